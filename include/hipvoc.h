@@ -1,0 +1,131 @@
+/*
+ * hipvoc.h -- C ABI of the MI355X-native vocoder backend (libhipvoc.so / libhipvoc.a).
+ *
+ * This is the drop-in boundary behind qwen3-tts' Vocoder worker role: the functions below are what
+ * a `#[cfg(feature = "hip-vocoder")] VocoderBackend::Hip` arm in src/worker/vocoder.rs binds over
+ * FFI (INTEGRATION.md shows the Rust side).  Conventions mirror the reference's existing native
+ * shim, cpp/code_pred_ggml_shim.cpp:11-75 as bound by src/worker/code_predictor_ggml.rs:15-26:
+ * opaque `void*` handle, NULL on load failure, `int` 0 on success / negative on error,
+ * caller-allocated outputs, explicit free.  No function aborts or throws across the boundary.
+ *
+ * Threading (src/worker/mod.rs:567-577,628-631): calls on one handle are serialised by the
+ * caller (the worker holds a tokio Mutex); a handle may be used from different threads over time.
+ * The library keeps no thread-local state and sets the HIP device on every call.
+ */
+#ifndef HIPVOC_H
+#define HIPVOC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* error codes (negative) */
+#define HIPVOC_OK 0
+#define HIPVOC_E_ARG (-1)       /* bad argument (null pointer, n_frames < 0, ...) */
+#define HIPVOC_E_CODE (-2)      /* a code index outside [0, codebook_size) */
+#define HIPVOC_E_CAP (-3)       /* output capacity too small */
+#define HIPVOC_E_STAGE (-4)     /* no such debug stage */
+#define HIPVOC_E_HIP (-5)       /* HIP runtime / launch failure (text in hipvoc_last_error) */
+#define HIPVOC_E_MODEL (-6)     /* weights file unreadable / unsupported architecture */
+
+#define HIPVOC_DTYPE_F32 0
+#define HIPVOC_DTYPE_BF16 1     /* bf16 conv-GEMM mode (reserved; hipvoc_load rejects it for now) */
+
+#define HIPVOC_SAMPLES_PER_TOKEN 1920   /* src/worker/vocoder.rs:6, src/protocol.rs:122 */
+
+/* Number of visible HIP devices (0 if none / runtime unavailable). */
+int hipvoc_device_count(void);
+
+/*
+ * Replaces OnnxVocoder::load (src/worker/vocoder.rs:137-162) + Vocoder::load (vocoder.rs:21-57).
+ * weights_path: a .safetensors file holding the upstream `decoder.*` tensors of the Qwen3-TTS
+ * speech tokenizer (F32/F16/BF16); architecture is derived from tensor shapes, the few
+ * hyper-parameters shapes cannot tell come from the file's __metadata__ (defaults: 16 heads,
+ * window 72, rope theta 1e4, rms eps 1e-5).
+ * unit_frames: frames per decode unit = the reference's `max_tokens` (ONNX input dim 1; 64).
+ * Returns NULL on failure; hipvoc_last_error(NULL) then holds the reason.
+ */
+void *hipvoc_load(const char *weights_path, int device_id, int dtype, int unit_frames);
+
+/* `pub max_tokens` of the reference's Vocoder (vocoder.rs:17). */
+int hipvoc_max_tokens(void *h);
+
+/* Samples one full unit produces: out_len(unit_frames) = 1920*unit_frames - 555 for the shipped
+ * topology (length of OnnxVocoder::run's output). */
+int64_t hipvoc_unit_samples(void *h);
+
+/*
+ * Replaces OnnxVocoder::run (vocoder.rs:164-172): one unit of exactly max_tokens frames
+ * (codes row-major [max_tokens, 16] i64, as fed to the ONNX session) -> hipvoc_unit_samples() f32.
+ */
+int hipvoc_run(void *h, const int64_t *codes, int max_tokens, float *out, size_t out_cap, size_t *n_out);
+
+/*
+ * Replaces the body of Vocoder::synthesize (vocoder.rs:60-85): splits n_frames into independent
+ * max_tokens-frame units, pads the last with code 0, decodes ALL units in one batched pass and
+ * keeps min(chunk_len*1920, unit_samples) samples of each, concatenated.  codes: [n_frames,16].
+ */
+int hipvoc_decode(void *h, const int64_t *codes, int n_frames, float *out, size_t out_cap, size_t *n_out);
+
+/*
+ * Batched form (many utterances per request).  codes: the B sequences
+ * concatenated ([sum n_frames, 16]); sequence b's samples are written at out + out_off[b]
+ * (capacity n_frames[b]*1920 each) and its sample count to n_out[b].  Every sequence is chunked
+ * exactly like hipvoc_decode, so results equal B separate calls bit for bit.
+ */
+int hipvoc_decode_batch(void *h, const int64_t *codes, const int32_t *n_frames, int B, float *out,
+                        const size_t *out_off, size_t *n_out);
+
+/*
+ * Replaces Worker::handle_vocode's payload handling (src/worker/mod.rs:507-531): codes arrive as
+ * i64 little-endian bytes ([n_frames,16]), audio leaves as i16 little-endian PCM,
+ * (s*32767.0).clamp(-32768.0,32767.0) as i16, converted on the GPU.  pcm capacity in samples.
+ */
+int hipvoc_vocode_pcm16(void *h, const uint8_t *codes_le, int n_frames, int16_t *pcm, size_t pcm_cap,
+                        size_t *n_samples);
+
+/*
+ * Device-resident batched units (what bench.py times): d_codes [n_units, max_tokens, 16] i64 and
+ * d_out [n_units, unit_stride] f32 are DEVICE pointers (unit_stride >= hipvoc_unit_samples, in
+ * floats).  Work is enqueued on the handle's stream; call hipvoc_sync to wait and collect
+ * deferred errors (out-of-range codes are detected on the device).
+ */
+int hipvoc_decode_units_device(void *h, const int64_t *d_codes, int n_units, float *d_out, size_t unit_stride);
+int hipvoc_sync(void *h);
+/* The hipStream_t the handle launches on (for hipEvent timing by the caller). */
+void *hipvoc_stream(void *h);
+
+/* Units decoded per pass (workspace is sized for this many; default 8, env HIPVOC_GROUP). */
+int hipvoc_group_units(void *h);
+
+/* Algorithmic work of one unit, recomputed from the loaded tensor shapes:
+ * multiply-accumulates of all GEMM-shaped stages. */
+int64_t hipvoc_unit_macs(void *h);
+
+/*
+ * Diagnostics for parity tests: output of intermediate stage `stage` for ONE unit of n_frames
+ * frames (no chunking; 1 <= n_frames <= max_tokens), channel-first [C][L] into out.
+ * Stage numbering = oracle/voc_oracle.c decoder_forward: 0 RVQ dequant, 1 pre_conv, 2 input_proj,
+ * 3.. transformer layers, then output_proj, upsample (2 each), decoder[0], 4 per decoder block,
+ * last = waveform.  Stage 1000 = raw dequant sums [2*256][T] (the bit-exact contract).
+ */
+int hipvoc_num_stages(void *h);
+int hipvoc_debug_stage(void *h, const int64_t *codes, int n_frames, int stage, float *out, size_t out_cap,
+                       int *C, int64_t *L);
+
+/* Per-kernel-family device time (ms) of the LAST hipvoc_decode_units_device group when profiling is
+ * on (env HIPVOC_PROFILE=1): names/ms arrays of length up to cap; returns the count. */
+int hipvoc_last_profile(void *h, const char **names, float *ms, double *flops, int cap);
+
+/* Text of the last error on this handle (or of the last failed hipvoc_load if h is NULL). */
+const char *hipvoc_last_error(void *h);
+
+void hipvoc_free(void *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

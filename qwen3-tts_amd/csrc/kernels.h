@@ -1,0 +1,67 @@
+// Launch interface of the gfx950 kernels (kernels.hip).  Host code (model.cpp) sees only this.
+//
+// Activation layout everywhere: channel-first, time-contiguous, batched over the G units of a pass:
+//   x[c][u][t]  at  x + c*(G*Lp) + u*Lp + t     (Lp = L rounded up to 4 floats)
+// so consecutive lanes of a wavefront touch consecutive time steps (coalesced), a causal tap is a
+// shift along the contiguous axis, and the MFMA "position" index lives on the lane.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hipvoc {
+
+enum Act { ACT_NONE = 0, ACT_GELU = 1, ACT_CLAMP1 = 2 };
+
+// Implicit-GEMM convolution family:  y[n][m] = epi( sum_tap sum_ci W[tap][ci][n] * pro(x[ci][m + shift(tap)]) )
+// rows n = output channel (x S output phases for transposed convs), columns m = time positions.
+struct ConvGemmArgs {
+    const float *x;
+    float *y;
+    const float *w;       // packed [ntaps][CinP][NP], CinP = roundup(Cin,32), NP = roundup(N, 32*TN)
+    const float *bias;    // [N/S] or null
+    const float *res;     // residual (layout of y) or null
+    const float *rscale;  // [N/S] scale on (acc+bias) before the residual add, or null
+    const float *sn_a;    // SnakeBeta prologue: exp(alpha)[Cin], or null
+    const float *sn_ib;   //                     1/(exp(beta)+1e-9)[Cin]
+    int Cin, N, NP, TN;
+    int ntaps, shift0, shift_step;   // shift(tap) = shift0 + tap*shift_step
+    int S;                           // out channel = n / S, out position = m*S + n % S
+    int units;                       // G (1 in flat mode)
+    int M;                           // GEMM columns per unit
+    int Lin;                         // valid input positions per unit
+    long x_us, x_cs, y_us, y_cs;     // unit / channel strides in floats
+    int act;
+};
+hipError_t launch_conv_gemm(const ConvGemmArgs &a, hipStream_t s);
+size_t conv_gemm_lds_bytes(const ConvGemmArgs &a);
+
+struct RvqArgs {
+    const long long *codes;   // [G][T][nq]
+    const float *embed;       // [nq][cb_size][D]  (embed_sum / clamp(usage,1e-5), done on the host)
+    const float *wf_t;        // [D][Q] transposed output_proj of the semantic group
+    const float *wr_t;        // [D][Q] ... acoustic group
+    float *out;               // [Q][G][Lp]
+    float *sums;              // optional [2D][G][Lp] raw sums (debug) or null
+    int *err;                 // device flag: set to 1 on an out-of-range code
+    int nq, cb_size, D, Q, T, Lp, G;
+};
+hipError_t launch_rvq(const RvqArgs &a, hipStream_t s);
+
+// RMSNorm over channels of x[C][P] (P flat positions, channel stride P): y = w * (x * rsqrt(mean x^2 + eps))
+hipError_t launch_rmsnorm(const float *x, float *y, const float *w, int C, long P, float eps, hipStream_t s);
+
+// Causal sliding-window attention with RoPE.  qkv[3*nh*hd][G][Lp] (rows: q | k | v), out[nh*hd][G][Lp].
+hipError_t launch_attention(const float *qkv, float *out, const float *cos_t, const float *sin_t, int nh, int hd,
+                            int G, int T, int Lp, int window, hipStream_t s);
+
+// g[i] = silu(g[i]) * u[i]  over n elements
+hipError_t launch_swiglu(float *g, const float *u, long n, hipStream_t s);
+
+// ConvNeXt front half: depthwise causal conv k=K then LayerNorm over channels (eps) with affine.
+hipError_t launch_dwconv_ln(const float *x, float *y, const float *dw_w, const float *dw_b, const float *ln_w,
+                            const float *ln_b, int C, int K, int G, int L, int Lp, float eps, hipStream_t s);
+
+// f32 -> i16 PCM: (s*32767.0).clamp(-32768.0, 32767.0) as i16   (src/worker/mod.rs:521-524)
+hipError_t launch_pcm16(const float *x, int16_t *y, long n, hipStream_t s);
+
+}  // namespace hipvoc
