@@ -116,9 +116,13 @@ int hipvoc_num_stages(void *h);
 int hipvoc_debug_stage(void *h, const int64_t *codes, int n_frames, int stage, float *out, size_t out_cap,
                        int *C, int64_t *L);
 
-/* Per-kernel-family device time (ms) of the LAST hipvoc_decode_units_device group when profiling is
- * on (env HIPVOC_PROFILE=1): names/ms arrays of length up to cap; returns the count. */
-int hipvoc_last_profile(void *h, const char **names, float *ms, double *flops, int cap);
+/* Per-step-family device time of the LAST pass (one group of units) when profiling is on
+ * (hipvoc_set_profile(h,1) or env HIPVOC_PROFILE=1): hipEvents are recorded on the handle's stream
+ * around every launch and the stream is synchronised after the pass.  names[i] is
+ * "<step>|<kernel symbol>", ms[i] the summed device time, flops[i] the summed algorithmic FLOPs
+ * (2 x MAC), launches[i] the launch count.  Arrays hold up to cap entries; returns the count. */
+int hipvoc_set_profile(void *h, int on);
+int hipvoc_last_profile(void *h, const char **names, float *ms, double *flops, int *launches, int cap);
 
 /* Text of the last error on this handle (or of the last failed hipvoc_load if h is NULL). */
 const char *hipvoc_last_error(void *h);

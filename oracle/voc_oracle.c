@@ -678,6 +678,19 @@ int voc_oracle_stage_shape(const VocOracle *o, int T, int stage, int *C, int64_t
     return -4;
 }
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+/* Number of OpenMP threads the oracle uses from now on (returns what is in effect). */
+int voc_oracle_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
 /* OnnxVocoder::run equivalent (vocoder.rs:164-172): one unit of exactly T frames, no chunking. */
 int voc_oracle_run_unit(VocOracle *o, const int64_t *codes, int T, float *out, size_t cap, size_t *n_out) {
     int64_t L = voc_oracle_out_len(o, T);

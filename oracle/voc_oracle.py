@@ -124,6 +124,10 @@ class Oracle:
         return out[: n.value]
 
 
+def set_threads(n: int) -> int:
+    return int(lib().voc_oracle_set_threads(int(n)))
+
+
 def pcm16(x: np.ndarray) -> np.ndarray:
     x = np.ascontiguousarray(x, dtype=np.float32)
     out = np.empty(x.size, dtype=np.int16)

@@ -50,6 +50,11 @@ struct Gemm {
     int Cin = 0, N = 0, NP = 0, TN = 0, ntaps = 1, shift0 = 0, step = 0, S = 1;
 };
 
+static const char *gemm_kernel_name(int tn) {
+    static const char *n[] = {"", "conv_gemm_kernel<1>", "conv_gemm_kernel<2>", "conv_gemm_kernel<3>", "conv_gemm_kernel<4>"};
+    return n[tn < 1 || tn > 4 ? 0 : tn];
+}
+
 static int pick_tn(int N) {
     // prefer the widest tile that divides N; else the one with the least padding (ties: wider)
     for (int tn = 4; tn >= 3; tn--)
@@ -70,6 +75,7 @@ struct Snake {
 struct Step {
     std::function<hipError_t(hipStream_t)> run;
     const char *name;
+    const char *kernel;    // device kernel symbol family (matches rocprofv3 kernel names)
     double macs;           // per pass (all G units)
     int stage;             // stage id this step completes, or -1
     const float *out;      // where that stage's tensor lives
@@ -130,6 +136,7 @@ struct Ctx {
     std::vector<std::string> prof_names;
     std::vector<float> prof_ms;
     std::vector<double> prof_flops;
+    std::vector<int> prof_launches;
 
     int64_t unit_macs = 0;
 
@@ -473,8 +480,8 @@ struct PlanBuilder {
         return (float *)ptr;
     }
 
-    void add(const char *name, double macs, std::function<hipError_t(hipStream_t)> f) {
-        p->steps.push_back(Step{std::move(f), name, macs, -1, nullptr, 0, 0, 0});
+    void add(const char *name, const char *kernel, double macs, std::function<hipError_t(hipStream_t)> f) {
+        p->steps.push_back(Step{std::move(f), name, kernel, macs, -1, nullptr, 0, 0, 0});
     }
     void mark(int stage, const float *out, int C, int L, int Lp) {
         Step &s = p->steps.back();
@@ -498,7 +505,7 @@ struct PlanBuilder {
         }
         a.x_cs = (long)G * Lpi; a.y_cs = (long)G * Lpo;
         double macs = (double)G * M * g.N * g.Cin * g.ntaps;
-        add(name, macs, [a](hipStream_t s) { return launch_conv_gemm(a, s); });
+        add(name, gemm_kernel_name(g.TN), macs, [a](hipStream_t s) { return launch_conv_gemm(a, s); });
     }
 };
 
@@ -519,7 +526,7 @@ static Plan *get_plan(Ctx *c, int G, int T) {
         a.embed = c->embed; a.wf_t = c->wf_t; a.wr_t = c->wr_t; a.out = rvq; a.sums = sums; a.err = c->d_err;
         a.nq = c->n_q; a.cb_size = c->cb_size; a.D = c->cb_dim; a.Q = c->q_out; a.T = T; a.Lp = Tp; a.G = G;
         Ctx *cc = c;
-        b.add("rvq", (double)G * T * 2 * c->cb_dim * c->q_out, [a, cc](hipStream_t s) {
+        b.add("rvq", "rvq_kernel", (double)G * T * 2 * c->cb_dim * c->q_out, [a, cc](hipStream_t s) {
             RvqArgs aa = a;
             aa.codes = cc->cur_codes;
             return launch_rvq(aa, s);
@@ -544,25 +551,25 @@ static Plan *get_plan(Ctx *c, int G, int T) {
             const Ctx::Layer &ly = c->layers[li];
             int H = c->hidden;
             float eps = c->rms_eps;
-            b.add("rmsnorm", 0, [=](hipStream_t s) { return launch_rmsnorm(h, xn, ly.ln1, H, P, eps, s); });
+            b.add("rmsnorm", "rmsnorm_kernel", 0, [=](hipStream_t s) { return launch_rmsnorm(h, xn, ly.ln1, H, P, eps, s); });
             b.gemm("qkv", ly.qkv, xn, T, Tp, qkv, Tp, nullptr, nullptr, nullptr, ACT_NONE);
             int nh = c->n_heads, hd = c->head_dim, win = c->window;
             const float *ct = c->cos_t, *sn = c->sin_t;
-            b.add("attention", (double)G * nh * T * T * hd, [=](hipStream_t s) {
+            b.add("attention", "attention_kernel", (double)G * nh * T * T * hd, [=](hipStream_t s) {
                 return launch_attention(qkv, ao, ct, sn, nh, hd, G, T, Tp, win, s);
             });
             b.gemm("o_proj", ly.o, ao, T, Tp, h, Tp, nullptr, h, ly.ls1, ACT_NONE);
-            b.add("rmsnorm", 0, [=](hipStream_t s) { return launch_rmsnorm(h, xn, ly.ln2, H, P, eps, s); });
+            b.add("rmsnorm", "rmsnorm_kernel", 0, [=](hipStream_t s) { return launch_rmsnorm(h, xn, ly.ln2, H, P, eps, s); });
             b.gemm("gate_up", ly.gu, xn, T, Tp, gu, Tp, nullptr, nullptr, nullptr, ACT_NONE);
             long nI = (long)c->inter * P;
-            b.add("swiglu", 0, [=](hipStream_t s) { return launch_swiglu(gu, gu + nI, nI, s); });
+            b.add("swiglu", "swiglu_kernel", 0, [=](hipStream_t s) { return launch_swiglu(gu, gu + nI, nI, s); });
             b.gemm("down", ly.down, gu, T, Tp, h, Tp, nullptr, h, ly.ls2, ACT_NONE);
             b.mark(st++, h, c->hidden, T, Tp);
         }
         const float *fw = c->final_norm;
         int H = c->hidden;
         float eps = c->rms_eps;
-        b.add("rmsnorm", 0, [=](hipStream_t s) { return launch_rmsnorm(h, xn, fw, H, P, eps, s); });
+        b.add("rmsnorm", "rmsnorm_kernel", 0, [=](hipStream_t s) { return launch_rmsnorm(h, xn, fw, H, P, eps, s); });
     } else {
         xn = h;
     }
@@ -603,7 +610,7 @@ static Plan *get_plan(Ctx *c, int G, int T) {
             float *y = t1;
             int CC = C, K = u.K, GG = G, LL = L, LLp = Lp;
             Ctx::Up uu = u;
-            b.add("dwconv_ln", (double)G * L * C * K, [=](hipStream_t s) {
+            b.add("dwconv_ln", "dwconv_ln_kernel", (double)G * L * C * K, [=](hipStream_t s) {
                 return launch_dwconv_ln(x, y, uu.dw_w, uu.dw_b, uu.ln_w, uu.ln_b, CC, K, GG, LL, LLp, 1e-6f, s);
             });
         }
@@ -644,7 +651,7 @@ static Plan *get_plan(Ctx *c, int G, int T) {
         a.Cin = g.Cin; a.N = g.N; a.NP = g.NP; a.TN = g.TN; a.ntaps = g.ntaps; a.shift0 = g.shift0; a.shift_step = g.step;
         a.S = 1; a.act = ACT_CLAMP1; a.units = G; a.M = L; a.Lin = L; a.x_us = Lp; a.x_cs = (long)G * Lp;
         Ctx *cc = c;
-        b.add("final_conv7", (double)G * L * g.Cin * g.ntaps, [a, cc](hipStream_t s) {
+        b.add("final_conv7", gemm_kernel_name(g.TN), (double)G * L * g.Cin * g.ntaps, [a, cc](hipStream_t s) {
             ConvGemmArgs aa = a;
             aa.y = cc->cur_out;
             aa.y_us = cc->cur_out_stride;
@@ -688,20 +695,23 @@ static int run_plan(Ctx *c, Plan *p, const long long *d_codes, float *d_out, lon
     }
     if (c->profile) {
         HIPCHK(hipStreamSynchronize(c->stream));
-        c->prof_names.clear(); c->prof_ms.clear(); c->prof_flops.clear();
+        c->prof_names.clear(); c->prof_ms.clear(); c->prof_flops.clear(); c->prof_launches.clear();
         for (size_t i = 0; i < ran; i++) {
             float ms = 0;
             HIPCHK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+            std::string key = std::string(p->steps[i].name) + "|" + p->steps[i].kernel;
             size_t k = 0;
             for (; k < c->prof_names.size(); k++)
-                if (c->prof_names[k] == p->steps[i].name) break;
+                if (c->prof_names[k] == key) break;
             if (k == c->prof_names.size()) {
-                c->prof_names.push_back(p->steps[i].name);
+                c->prof_names.push_back(key);
                 c->prof_ms.push_back(0);
                 c->prof_flops.push_back(0);
+                c->prof_launches.push_back(0);
             }
             c->prof_ms[k] += ms;
             c->prof_flops[k] += 2.0 * p->steps[i].macs;
+            c->prof_launches[k] += 1;
         }
         for (auto &e : ev) (void)hipEventDestroy(e);
     }
@@ -998,7 +1008,14 @@ int hipvoc_debug_stage(void *h, const int64_t *codes, int n_frames, int stage, f
     return HIPVOC_OK;
 }
 
-int hipvoc_last_profile(void *h, const char **names, float *ms, double *flops, int cap) {
+int hipvoc_set_profile(void *h, int on) {
+    Ctx *c = (Ctx *)h;
+    if (!c) return HIPVOC_E_ARG;
+    c->profile = on != 0;
+    return HIPVOC_OK;
+}
+
+int hipvoc_last_profile(void *h, const char **names, float *ms, double *flops, int *launches, int cap) {
     Ctx *c = (Ctx *)h;
     if (!c) return HIPVOC_E_ARG;
     int n = (int)c->prof_names.size();
@@ -1006,6 +1023,7 @@ int hipvoc_last_profile(void *h, const char **names, float *ms, double *flops, i
         if (names) names[i] = c->prof_names[i].c_str();
         if (ms) ms[i] = c->prof_ms[i];
         if (flops) flops[i] = c->prof_flops[i];
+        if (launches) launches[i] = c->prof_launches[i];
     }
     return n;
 }

@@ -22,7 +22,7 @@ EXPORTS = [
     "hipvoc_device_count", "hipvoc_load", "hipvoc_max_tokens", "hipvoc_unit_samples", "hipvoc_run",
     "hipvoc_decode", "hipvoc_decode_batch", "hipvoc_vocode_pcm16", "hipvoc_decode_units_device", "hipvoc_sync",
     "hipvoc_stream", "hipvoc_group_units", "hipvoc_unit_macs", "hipvoc_num_stages", "hipvoc_debug_stage",
-    "hipvoc_last_profile", "hipvoc_last_error", "hipvoc_free",
+    "hipvoc_set_profile", "hipvoc_last_profile", "hipvoc_last_error", "hipvoc_free",
 ]
 
 
@@ -67,7 +67,8 @@ def load_library():
     L.hipvoc_unit_macs.argtypes = [vp]
     L.hipvoc_num_stages.argtypes = [vp]
     L.hipvoc_debug_stage.argtypes = [vp, i64p, C.c_int, C.c_int, vp, sz, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
-    L.hipvoc_last_profile.argtypes = [vp, vp, vp, vp, C.c_int]
+    L.hipvoc_set_profile.argtypes = [vp, C.c_int]
+    L.hipvoc_last_profile.argtypes = [vp, vp, vp, vp, vp, C.c_int]
     L.hipvoc_last_error.restype = C.c_char_p
     L.hipvoc_last_error.argtypes = [vp]
     L.hipvoc_free.argtypes = [vp]
@@ -186,10 +187,15 @@ class HipVocoder:
                                                out.size, C.byref(c), C.byref(l)))
         return out[: c.value * l.value].reshape(c.value, l.value).copy()
 
-    def last_profile(self) -> Dict[str, Tuple[float, float]]:
+    def set_profile(self, on: bool):
+        self._check(self._L.hipvoc_set_profile(self._h, 1 if on else 0))
+
+    def last_profile(self) -> Dict[str, Tuple[float, float, int]]:
+        """{"<step>|<kernel symbol>": (ms, algorithmic flops, launches)} of the last pass."""
         cap = 128
         names = (C.c_char_p * cap)()
         ms = (C.c_float * cap)()
         fl = (C.c_double * cap)()
-        n = self._L.hipvoc_last_profile(self._h, names, ms, fl, cap)
-        return {names[i].decode(): (float(ms[i]), float(fl[i])) for i in range(min(n, cap))}
+        ln = (C.c_int * cap)()
+        n = self._L.hipvoc_last_profile(self._h, names, ms, fl, ln, cap)
+        return {names[i].decode(): (float(ms[i]), float(fl[i]), int(ln[i])) for i in range(min(n, cap))}

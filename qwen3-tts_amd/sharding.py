@@ -1,0 +1,55 @@
+"""Multi-GPU partitioning of the vocoder path: independent units, no exchange step.
+
+In the reference every ``max_tokens``-frame unit of every request is decoded with no carried state
+(src/worker/vocoder.rs:65-82), so both a batch of utterances and the segments of one long stream
+shard as contiguous ranges of units, one process per GPU.  The only communication is the optional
+gather of finished waveform shards to rank 0 (``torch.distributed`` all_gather_object / gather; with
+the ``nccl`` backend that is RCCL over xGMI, with ``gloo`` it runs on CPU for tests).
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Sequence, Tuple
+
+import numpy as np
+
+SAMPLES_PER_TOKEN = 1920
+
+
+def unit_spans(n_frames: int, unit_frames: int) -> List[Tuple[int, int]]:
+    """[(start_frame, end_frame)] of the reference's chunk loop (vocoder.rs:65-67)."""
+    return [(s, min(s + unit_frames, n_frames)) for s in range(0, n_frames, unit_frames)]
+
+
+def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous, balanced [lo, hi) of n_items for this rank (first n_items % world ranks get one more)."""
+    q, r = divmod(n_items, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def decode_stream_shard(synthesize: Callable[[np.ndarray], np.ndarray], codes: np.ndarray, unit_frames: int,
+                        rank: int, world: int) -> np.ndarray:
+    """This rank's part of one long code stream [n_frames,16]: the frames of its contiguous unit range,
+    decoded with the ordinary chunking.  Because shards start on unit boundaries, concatenating the
+    ranks' results in rank order is bit-identical to a single-GPU decode ("seam-exact stitching")."""
+    spans = unit_spans(codes.shape[0], unit_frames)
+    lo, hi = shard_range(len(spans), rank, world)
+    if lo == hi:
+        return np.zeros(0, dtype=np.float32)
+    return synthesize(codes[spans[lo][0]: spans[hi - 1][1]])
+
+
+def gather_stream(local: np.ndarray, rank: int, world: int, dist=None) -> np.ndarray | None:
+    """Assemble the shards on rank 0 (returns None elsewhere).  dist = torch.distributed (initialised)."""
+    if world == 1:
+        return local
+    parts = [None] * world if rank == 0 else None
+    dist.gather_object(local, parts, dst=0)
+    if rank != 0:
+        return None
+    return np.concatenate(parts)
+
+
+def shard_utterances(n_utts: int, rank: int, world: int) -> range:
+    lo, hi = shard_range(n_utts, rank, world)
+    return range(lo, hi)

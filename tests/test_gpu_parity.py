@@ -1,0 +1,249 @@
+"""GPU parity tests: the HIP path, called through the C ABI (ctypes on libhipvoc.so), against the CPU
+oracle on the same seeded inputs, against the committed golden fixtures, and -- at full size --
+through size-independent properties (unit independence, sharded stitching, determinism).
+
+Tolerances (BASELINE.json north_star): RVQ dequantisation bit-exact; fp32 waveform max-abs <= 1e-3 and
+SNR >= 60 dB versus the fp32 CPU path.
+"""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, oracle_for, snr_db, weights_for
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _torch_hip_first():
+    """torch ships its own HIP runtime: initialise it BEFORE libhipvoc pulls in the system one, the
+    same order bench.py uses (device tensors for the device-resident entry point come from torch)."""
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.init()
+    yield
+
+WAV_MAX_ABS = 1e-3
+WAV_SNR_DB = 60.0
+STAGE_MAX_ABS = 1e-3
+
+_VOC = {}
+
+
+def voc_for(pkg, synth, cfg_name, seed, unit):
+    key = (cfg_name, int(seed), int(unit))
+    if key not in _VOC:
+        cfg = getattr(synth, cfg_name)
+        path = os.path.join(tempfile.gettempdir(), f"hipvoc_test_{cfg_name}_{seed}.safetensors")
+        if not os.path.exists(path):
+            synth.save_safetensors(path, weights_for(synth, cfg_name, seed), cfg.metadata())
+        _VOC[key] = pkg.HipVocoder.load(path, device=0, unit_frames=unit)
+    return _VOC[key]
+
+
+def pad16(codes, cfg):
+    """The wire/ABI layout is [n,16]; configs here all use 16 codebooks."""
+    assert cfg.num_quantizers == 16
+    return codes
+
+
+# ------------------------------------------------------------------------------------ dequantisation
+@pytest.mark.parametrize("cfg_name", ["SMALL", "ODD", "FULL"])
+def test_rvq_dequant_bit_exact(pkg, synth, vo, cfg_name):
+    cfg = getattr(synth, cfg_name)
+    T = 7
+    v = voc_for(pkg, synth, cfg_name, 0, T)
+    o = oracle_for(vo, synth, cfg_name, 0)
+    codes = synth.make_codes(T, 11, cfg)
+    codes[0, :] = 0
+    codes[1, :] = cfg.codebook_size - 1
+    codes[2, 0] = 3                         # cluster_usage == 0 -> clamp(1e-5) path
+    codes[3, :] = 7 if cfg.codebook_size > 7 else 0   # a usage < 1e-5 row (every 7th+ entry)
+    sums_ref = o.stage(codes, 1000)
+    sums = v.stage(codes, 1000, sums_ref.size + 8)
+    assert sums.shape == sums_ref.shape
+    assert np.array_equal(sums.view(np.uint32), sums_ref.view(np.uint32)), "dequant sums differ bitwise"
+    q_ref = o.stage(codes, 0)
+    q = v.stage(codes, 0, q_ref.size + 8)
+    assert np.array_equal(q.view(np.uint32), q_ref.view(np.uint32)), "projected dequant output differs bitwise"
+
+
+# ------------------------------------------------------------------------------------ every stage
+@pytest.mark.parametrize("cfg_name,T", [("SMALL", 5), ("ODD", 9), ("SMALL", 8)])
+def test_every_stage_matches_oracle(pkg, synth, vo, cfg_name, T):
+    cfg = getattr(synth, cfg_name)
+    v = voc_for(pkg, synth, cfg_name, 0, T)
+    o = oracle_for(vo, synth, cfg_name, 0)
+    codes = synth.make_codes(T, 21 + T, cfg)
+    assert v.n_stages == o.n_stages
+    for s in range(v.n_stages):
+        ref = o.stage(codes, s)
+        got = v.stage(codes, s, ref.size + 8)
+        assert got.shape == ref.shape, s
+        assert np.abs(got - ref).max() <= STAGE_MAX_ABS, f"stage {s}"
+
+
+# ------------------------------------------------------------------------------------ golden fixtures
+@pytest.mark.parametrize("name", ["small_T5", "small_T3_edge", "odd_T9", "full_T3"])
+def test_unit_matches_golden(pkg, synth, name):
+    g = load_golden(name)
+    T = g["codes"].shape[0]
+    v = voc_for(pkg, synth, str(g["cfg"]), int(g["wseed"]), T)
+    wav = v.run(g["codes"])
+    assert wav.size == g["wav"].size
+    assert np.abs(wav - g["wav"]).max() <= WAV_MAX_ABS
+    assert snr_db(g["wav"], wav) >= WAV_SNR_DB
+    for s in range(int(g["n_stages"])):
+        shp = tuple(int(x) for x in g[f"s{s}_shape"][-2:])
+        got = v.stage(g["codes"], s, shp[0] * shp[1] + 8)
+        assert got.shape == shp
+        assert np.abs(got.reshape(-1)[g[f"s{s}_idx"]] - g[f"s{s}_val"]).max() <= STAGE_MAX_ABS, f"stage {s}"
+
+
+@pytest.mark.parametrize("name", ["small_chunks_10x4", "small_chunks_8x4"])
+def test_chunk_loop_matches_golden(pkg, synth, name):
+    g = load_golden(name)
+    v = voc_for(pkg, synth, str(g["cfg"]), int(g["wseed"]), int(g["max_tokens"]))
+    wav = v.synthesize(g["codes"])
+    assert wav.size == g["wav"].size
+    assert np.abs(wav - g["wav"]).max() <= WAV_MAX_ABS
+    assert snr_db(g["wav"], wav) >= WAV_SNR_DB
+
+
+# ------------------------------------------------------------------------------------ ragged / edge inputs
+def test_ragged_lengths_and_batch_equals_separate_calls(pkg, synth, vo):
+    cfg = synth.SMALL
+    unit = 4
+    v = voc_for(pkg, synth, "SMALL", 0, unit)
+    o = oracle_for(vo, synth, "SMALL", 0)
+    lens = [0, 1, 3, 4, 5, 8, 9, 37]      # empty, sub-unit, exact unit, unit+1, multiples, > one pass (group=8)
+    seqs = [synth.make_codes(n, 300 + n, cfg) for n in lens]
+    batch = v.synthesize_batch(seqs)
+    for n, c, got in zip(lens, seqs, batch):
+        single = v.synthesize(c, n)
+        assert np.array_equal(single, got), f"batch != single for n={n}"
+        if n == 0:
+            assert got.size == 0
+            continue
+        full, rem = divmod(n, unit)
+        assert got.size == full * cfg.out_len(unit) + rem * 1920
+        ref = o.synthesize(c, unit)
+        assert np.abs(got - ref).max() <= WAV_MAX_ABS
+        assert snr_db(ref, got) >= WAV_SNR_DB
+
+
+def test_error_codes_and_recovery(pkg, synth):
+    cfg = synth.SMALL
+    v = voc_for(pkg, synth, "SMALL", 0, 4)
+    good = synth.make_codes(6, 5, cfg)
+    bad = good.copy()
+    bad[4, 9] = cfg.codebook_size
+    with pytest.raises(pkg.HipVocError) as e:
+        v.synthesize(bad)
+    assert e.value.code == -2
+    neg = good.copy()
+    neg[0, 0] = -1
+    with pytest.raises(pkg.HipVocError) as e:
+        v.synthesize(neg)
+    assert e.value.code == -2
+    # capacity too small
+    import ctypes as C
+    out = np.empty(100, dtype=np.float32)
+    n = C.c_size_t(0)
+    rc = v._L.hipvoc_decode(v._h, good.ctypes.data, 6, out.ctypes.data, out.size, C.byref(n))
+    assert rc == -3
+    # the handle keeps serving (FFI never aborts: mod.rs:246-258 turns errors into error responses)
+    a = v.synthesize(good)
+    assert a.size == cfg.out_len(4) + 2 * 1920
+
+
+def test_device_resident_path_flags_bad_codes(pkg, synth):
+    import torch
+    cfg = synth.SMALL
+    v = voc_for(pkg, synth, "SMALL", 0, 4)
+    codes = synth.make_codes(4, 5, cfg).reshape(1, 4, 16)
+    codes[0, 2, 3] = cfg.codebook_size + 5
+    d_codes = torch.from_numpy(codes).cuda()
+    stride = (v.unit_samples + 63) // 64 * 64
+    d_out = torch.empty((1, stride), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    v.decode_units_device(d_codes.data_ptr(), 1, d_out.data_ptr(), stride)
+    with pytest.raises(pkg.HipVocError) as e:
+        v.sync()
+    assert e.value.code == -2
+    v.sync()     # flag is cleared
+
+
+def test_pcm16_path_bit_exact(pkg, synth, vo):
+    """handle_vocode: LE i64 bytes in, LE i16 PCM out; conversion on the GPU must equal mod.rs:521-524."""
+    cfg = synth.SMALL
+    v = voc_for(pkg, synth, "SMALL", 0, 4)
+    codes = synth.make_codes(9, 8, cfg)
+    wav = v.synthesize(codes)
+    pcm_bytes, n = v.handle_vocode(codes.astype("<i8").tobytes(), 9)
+    assert n == wav.size and len(pcm_bytes) == 2 * n
+    assert np.array_equal(np.frombuffer(pcm_bytes, dtype="<i2"), vo.pcm16(wav))
+
+
+def test_pad_frames_are_code_zero(pkg, synth):
+    """A 3-frame tail must equal the first 3*1920 samples of the unit padded with code 0 explicitly."""
+    cfg = synth.SMALL
+    v = voc_for(pkg, synth, "SMALL", 0, 4)
+    c = synth.make_codes(3, 9, cfg)
+    padded = np.zeros((4, 16), dtype=np.int64)
+    padded[:3] = c
+    assert np.array_equal(v.synthesize(c), v.run(padded)[: 3 * 1920])
+
+
+def test_window_binds_when_unit_is_longer_than_window(pkg, synth, vo):
+    """ODD has sliding_window 5; a 23-frame unit exercises the kv > q - window mask and 2 query blocks... """
+    cfg = synth.ODD
+    v = voc_for(pkg, synth, "ODD", 0, 40)
+    o = oracle_for(vo, synth, "ODD", 0)
+    codes = synth.make_codes(40, 3, cfg)
+    ref = o.run_unit(codes)
+    got = v.run(codes)
+    assert np.abs(got - ref).max() <= WAV_MAX_ABS
+    assert snr_db(ref, got) >= WAV_SNR_DB
+
+
+# ------------------------------------------------------------------------------------ full size
+def test_full_single_utterance_matches_oracle(pkg, synth, vo):
+    """BASELINE configs[1]: one 10 s utterance (125 frames -> units of 64 + 61), fp32, full model."""
+    cfg = synth.FULL
+    v = voc_for(pkg, synth, "FULL", 0, 64)
+    o = oracle_for(vo, synth, "FULL", 0)
+    codes = synth.make_codes(125, 1000, cfg)
+    got = v.synthesize(codes)
+    ref = o.synthesize(codes, 64)
+    assert got.size == ref.size == 122325 + 61 * 1920
+    err = np.abs(got - ref).max()
+    assert err <= WAV_MAX_ABS, err
+    assert snr_db(ref, got) >= WAV_SNR_DB
+    assert np.abs(ref).max() < 1.0 and ref.std() > 0.02, "reference must be a non-trivial, unclipped signal"
+
+
+def test_full_size_properties_batch_and_sharded_stream(pkg, synth):
+    """Size-independent properties at BASELINE sizes (no oracle): determinism, unit independence
+    (a unit decodes identically in any batch slot / group), and seam-exact stitching of a long
+    stream decoded as 1, 2, 4 and 8 contiguous shards (configs[3] semantics on one GPU)."""
+    cfg = synth.FULL
+    v = voc_for(pkg, synth, "FULL", 0, 64)
+    sh = pkg.sharding
+    stream = synth.make_codes(64 * 19 + 12, 4242, cfg)          # 20 units: 19 full + a 12-frame tail
+    whole = v.synthesize(stream)
+    assert whole.size == 19 * 122325 + 12 * 1920
+    assert np.array_equal(whole, v.synthesize(stream)), "non-deterministic"
+    assert np.all(np.abs(whole) <= 1.0)
+    for world in (2, 4, 8):
+        parts = [sh.decode_stream_shard(v.synthesize, stream, 64, r, world) for r in range(world)]
+        assert np.array_equal(np.concatenate(parts), whole), f"stitching differs at world={world}"
+    # unit independence: unit 5 alone == unit 5 inside the stream
+    alone = v.synthesize(stream[5 * 64: 6 * 64])
+    assert np.array_equal(alone, whole[5 * 122325: 6 * 122325])
+    # batch of utterances == separate calls
+    utts = [synth.make_codes(125, 1000 + u, cfg) for u in range(5)]
+    for got, c in zip(v.synthesize_batch(utts), utts):
+        assert np.array_equal(got, v.synthesize(c))
