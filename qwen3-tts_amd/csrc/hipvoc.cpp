@@ -90,8 +90,9 @@ struct Plan {
 struct Ctx {
     int device = 0;
     int unit_frames = 64;
-    int group = 8;
+    int group = 32;
     bool profile = false;
+    bool fuse_res = true;
     hipStream_t stream = nullptr;
     std::string err;
     std::vector<void *> dev_allocs;
@@ -114,6 +115,7 @@ struct Ctx {
     struct Block { Snake s; Gemm tc; Res res[3]; };
     std::vector<Block> blocks;
     Snake fin_snake;
+    float *fin_w_raw = nullptr;   // [C][K] for the dedicated final-stage kernel
     float *cos_t = nullptr, *sin_t = nullptr;
     int *d_err = nullptr;
 
@@ -182,8 +184,11 @@ struct Loader {
     float *upload(const std::vector<float> &v) {
         if (!ok) return nullptr;
         void *p = nullptr;
-        size_t bytes = std::max<size_t>(v.size(), 4) * sizeof(float);
+        // every tensor gets 256 trailing zero floats: per-channel vectors may be read up to the padded
+        // row count NP of a tile without guards
+        size_t bytes = (v.size() + 256) * sizeof(float);
         hipError_t e = hipMalloc(&p, bytes);
+        if (e == hipSuccess) e = hipMemset(p, 0, bytes);
         if (e == hipSuccess) e = hipMemcpy(p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice);
         if (e != hipSuccess) {
             err = std::string("device upload failed: ") + hipGetErrorString(e);
@@ -427,6 +432,12 @@ static bool load_model(Ctx *c, const char *path, std::string &err) {
     c->fin = L.conv({D + fmt("decoder.%d.conv.weight", nb + 2)}, D + fmt("decoder.%d.conv.bias", nb + 2), 1);
     if (!L.ok) { err = L.err; return false; }
     if (c->fin.N != 1) { err = "final conv must have one output channel"; return false; }
+    {
+        std::vector<float> w;
+        std::vector<int64_t> sh;
+        if (!L.get(D + fmt("decoder.%d.conv.weight", nb + 2), w, sh)) { err = L.err; return false; }
+        c->fin_w_raw = L.upload(w);
+    }
 
     // RoPE tables (TF:2419-2433): inv_freq = 1/theta^(2d/hd) fp32; cos/sin of inv_freq*pos in fp32
     if (c->n_layers) {
@@ -505,7 +516,25 @@ struct PlanBuilder {
         }
         a.x_cs = (long)G * Lpi; a.y_cs = (long)G * Lpo;
         double macs = (double)G * M * g.N * g.Cin * g.ntaps;
-        add(name, gemm_kernel_name(g.TN), macs, [a](hipStream_t s) { return launch_conv_gemm(a, s); });
+        add(name, conv_gemm_kernel_name(a), macs, [a](hipStream_t s) { return launch_conv_gemm(a, s); });
+    }
+
+    // fused residual unit: y = x + c2(snake2(c1(snake1(x)))) in one launch (in place on x is NOT allowed:
+    // other workgroups still read x's halo, so y must be a different buffer)
+    static bool can_fuse(const Gemm &c1, const Gemm &c2) {
+        return c1.S == 1 && c2.S == 1 && c2.ntaps == 1 && c2.Cin == c1.N && c2.N == c1.N && c1.NP == c2.NP &&
+               c1.NP / 32 <= 6 && c1.NP / 32 != 5 && (c1.N + 31) / 32 == c1.NP / 32 && c1.bias && c2.bias;
+    }
+    void res_unit_fused(const char *name, const Gemm &c1, const Gemm &c2, const Snake &s1, const Snake &s2, const float *x,
+                        int L, int Lp, float *y) {
+        ConvGemmArgs a{};
+        a.x = x; a.y = y; a.w = c1.w; a.bias = c1.bias; a.res = x; a.sn_a = s1.ea; a.sn_ib = s1.ib;
+        a.w2 = c2.w; a.bias2 = c2.bias; a.sn2_a = s2.ea; a.sn2_ib = s2.ib;
+        a.Cin = c1.Cin; a.N = c1.N; a.NP = c1.NP; a.TN = c1.TN;
+        a.ntaps = c1.ntaps; a.shift0 = c1.shift0; a.shift_step = c1.step; a.S = 1; a.act = ACT_NONE;
+        a.units = G; a.M = L; a.Lin = L; a.x_us = Lp; a.y_us = Lp; a.x_cs = (long)G * Lp; a.y_cs = (long)G * Lp;
+        double macs = (double)G * L * c1.N * ((double)c1.Cin * c1.ntaps + c2.Cin);
+        add(name, conv_gemm_kernel_name(a), macs, [a](hipStream_t s) { return launch_conv_gemm(a, s); });
     }
 };
 
@@ -626,6 +655,7 @@ static Plan *get_plan(Ctx *c, int G, int T) {
     // g6
     static const char *tc_names[] = {"b0_transconv", "b1_transconv", "b2_transconv", "b3_transconv", "bN_transconv"};
     static const char *c7_names[] = {"b0_conv7", "b1_conv7", "b2_conv7", "b3_conv7", "bN_conv7"};
+    static const char *ru_names[] = {"b0_resunit", "b1_resunit", "b2_resunit", "b3_resunit", "bN_resunit"};
     static const char *c1_names[] = {"b0_conv1", "b1_conv1", "b2_conv1", "b3_conv1", "bN_conv1"};
     for (size_t bi = 0; bi < c->blocks.size(); bi++) {
         const Ctx::Block &blk = c->blocks[bi];
@@ -638,20 +668,34 @@ static Plan *get_plan(Ctx *c, int G, int T) {
         b.mark(st++, cur, C, L, Lp);
         for (int u = 0; u < 3; u++) {
             const Ctx::Res &ru = blk.res[u];
-            b.gemm(c7_names[ni], ru.c1, cur, L, Lp, t1, Lp, &ru.s1, nullptr, nullptr, ACT_NONE);
-            b.gemm(c1_names[ni], ru.c2, t1, L, Lp, cur, Lp, &ru.s2, cur, nullptr, ACT_NONE);
+            if (c->fuse_res && PlanBuilder::can_fuse(ru.c1, ru.c2)) {
+                b.res_unit_fused(ru_names[ni], ru.c1, ru.c2, ru.s1, ru.s2, cur, L, Lp, t1);
+                std::swap(cur, t1);
+            } else {
+                b.gemm(c7_names[ni], ru.c1, cur, L, Lp, t1, Lp, &ru.s1, nullptr, nullptr, ACT_NONE);
+                b.gemm(c1_names[ni], ru.c2, t1, L, Lp, cur, Lp, &ru.s2, cur, nullptr, ACT_NONE);
+            }
             b.mark(st++, cur, C, L, Lp);
         }
     }
     // g7: final snake + conv -> 1 channel + clamp, written straight to the caller's buffer
-    {
+    if (c->fin.ntaps == 7) {
+        const Gemm &g = c->fin;
+        const float *x = cur, *w = c->fin_w_raw, *bias = g.bias, *sa = c->fin_snake.ea, *sib = c->fin_snake.ib;
+        int Cf = g.Cin, GG = G, LL = L, LLp = Lp;
+        Ctx *cc = c;
+        b.add("final_conv7", "final_conv_kernel<7>", (double)G * L * g.Cin * g.ntaps, [=](hipStream_t s) {
+            return launch_final_conv(x, cc->cur_out, w, bias, sa, sib, Cf, 7, GG, LL, LLp, cc->cur_out_stride, s);
+        });
+        b.mark(st++, nullptr, 1, L, 0);
+    } else {
         ConvGemmArgs a{};
         const Gemm &g = c->fin;
         a.x = cur; a.w = g.w; a.bias = g.bias; a.sn_a = c->fin_snake.ea; a.sn_ib = c->fin_snake.ib;
         a.Cin = g.Cin; a.N = g.N; a.NP = g.NP; a.TN = g.TN; a.ntaps = g.ntaps; a.shift0 = g.shift0; a.shift_step = g.step;
         a.S = 1; a.act = ACT_CLAMP1; a.units = G; a.M = L; a.Lin = L; a.x_us = Lp; a.x_cs = (long)G * Lp;
         Ctx *cc = c;
-        b.add("final_conv7", gemm_kernel_name(g.TN), (double)G * L * g.Cin * g.ntaps, [a, cc](hipStream_t s) {
+        b.add("final_conv", conv_gemm_kernel_name(a), (double)G * L * g.Cin * g.ntaps, [a, cc](hipStream_t s) {
             ConvGemmArgs aa = a;
             aa.y = cc->cur_out;
             aa.y_us = cc->cur_out_stride;
@@ -822,6 +866,7 @@ void *hipvoc_load(const char *weights_path, int device_id, int dtype, int unit_f
     c->unit_frames = unit_frames;
     if (const char *g = getenv("HIPVOC_GROUP")) c->group = std::max(1, std::min(64, atoi(g)));
     if (const char *pf = getenv("HIPVOC_PROFILE")) c->profile = atoi(pf) != 0;
+    if (const char *fz = getenv("HIPVOC_FUSE")) c->fuse_res = atoi(fz) != 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
     std::string err;
     if (!load_model(c.get(), weights_path, err)) return fail(err);

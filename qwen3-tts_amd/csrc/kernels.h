@@ -23,6 +23,11 @@ struct ConvGemmArgs {
     const float *rscale;  // [N/S] scale on (acc+bias) before the residual add, or null
     const float *sn_a;    // SnakeBeta prologue: exp(alpha)[Cin], or null
     const float *sn_ib;   //                     1/(exp(beta)+1e-9)[Cin]
+    // fused residual unit (w2 != null): y = res + W2 * snake2(conv(snake(x)) + bias) + bias2
+    const float *w2;      // packed 1x1 conv [1][roundup(N,32)][NP]
+    const float *bias2;   // [N] or null
+    const float *sn2_a;   // [N]
+    const float *sn2_ib;  // [N]
     int Cin, N, NP, TN;
     int ntaps, shift0, shift_step;   // shift(tap) = shift0 + tap*shift_step
     int S;                           // out channel = n / S, out position = m*S + n % S
@@ -31,8 +36,11 @@ struct ConvGemmArgs {
     int Lin;                         // valid input positions per unit
     long x_us, x_cs, y_us, y_cs;     // unit / channel strides in floats
     int act;
+    int dbg;                         // timing-only ablation bits (set by the launcher from HIPVOC_DBG; 0 in production)
 };
 hipError_t launch_conv_gemm(const ConvGemmArgs &a, hipStream_t s);
+// kernel symbol family actually launched for these args (profiling labels)
+const char *conv_gemm_kernel_name(const ConvGemmArgs &a);
 size_t conv_gemm_lds_bytes(const ConvGemmArgs &a);
 
 struct RvqArgs {
@@ -60,6 +68,10 @@ hipError_t launch_swiglu(float *g, const float *u, long n, hipStream_t s);
 // ConvNeXt front half: depthwise causal conv k=K then LayerNorm over channels (eps) with affine.
 hipError_t launch_dwconv_ln(const float *x, float *y, const float *dw_w, const float *dw_b, const float *ln_w,
                             const float *ln_b, int C, int K, int G, int L, int Lp, float eps, hipStream_t s);
+
+// Final stage: SnakeBeta -> causal conv C->1 (w[C][K], K == 7; other K: use conv_gemm) -> clamp; out[u*out_stride + t]
+hipError_t launch_final_conv(const float *x, float *out, const float *w, const float *bias, const float *sn_a,
+                             const float *sn_ib, int C, int K, int G, int L, int Lp, long out_stride, hipStream_t s);
 
 // f32 -> i16 PCM: (s*32767.0).clamp(-32768.0, 32767.0) as i16   (src/worker/mod.rs:521-524)
 hipError_t launch_pcm16(const float *x, int16_t *y, long n, hipStream_t s);

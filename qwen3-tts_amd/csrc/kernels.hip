@@ -8,30 +8,89 @@
 // re-read ONE LDS halo tile at shifted offsets, and evaluates SnakeBeta once per staged element.
 #include "kernels.h"
 
+#include <cstdio>
+#include <cstdlib>
+
 namespace hipvoc {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-static constexpr int BM = 256;   // time positions per workgroup (4 waves x 64)
-static constexpr int BK = 32;    // input channels per K stage
+static constexpr int BM = 256;   // time positions per workgroup (8 waves x 32)
+static constexpr int BK = 16;    // input channels per K stage
+
+// sin(t)^2 for SnakeBeta.  Quadrant reduction n = rint(t*2/pi), r = t - n*pi/2 by a three-constant
+// Cody-Waite fma chain (exact cancellation under fma; good to |t| ~ 1e5), then the sin or cos
+// minimax polynomial on [-pi/4, pi/4]; the sign is irrelevant because the result is squared.
+// Max error of sin/cos here ~1 ulp, i.e. the same class as libm's sinf the CPU oracle uses.
+__device__ __forceinline__ float sin_sq(float t) {
+    float n = __builtin_rintf(t * 0.63661977236758134308f);
+    float r = __builtin_fmaf(n, -1.57079625129699707031e+00f, t);
+    r = __builtin_fmaf(n, -7.54978941586159635335e-08f, r);
+    r = __builtin_fmaf(n, -5.39030252995776476554e-15f, r);
+    float r2 = r * r;
+    // sin(r) = r + r^3 * S(r^2),  cos(r) = 1 - r^2/2 + r^4 * C(r^2)
+    float sp = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(2.86567956e-6f, r2, -1.98559923e-4f), r2, 8.33338592e-3f), r2, -1.66666672e-1f);
+    float sv = __builtin_fmaf(r * r2, sp, r);
+    float cp = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(2.44677067e-5f, r2, -1.38877297e-3f), r2, 4.16666567e-2f), r2, -0.5f);
+    float cv = __builtin_fmaf(r2, cp, 1.0f);
+    int q = (int)n;
+    float v = (q & 1) ? cv : sv;
+    return v * v;
+}
+
+// Makes a (wave-uniform) pointer opaque at this point of the program, so loads through it cannot be
+// hoisted above it (hipcc otherwise lifts every epilogue constant load over the whole K loop and
+// keeps dozens of registers live).
+// (The pointer itself stays a kernel argument, so the loads stay global_load; only a zero offset
+// goes through the asm.)
+template <typename T>
+__device__ __forceinline__ T *launder(T *p) {
+    long z = 0;
+    asm volatile("" : "+s"(z));
+    return p ? p + z : p;
+}
+// Same, and additionally not before `dep` has been computed (pins the point in program order).
+template <typename T>
+__device__ __forceinline__ T *launder_after(T *p, float dep) {
+    long z = 0;
+    asm volatile("" : "+s"(z) : "v"(dep));
+    return p ? p + z : p;
+}
+
+__device__ __forceinline__ float snake_beta(float x, float ea, float ib) { return x + ib * sin_sq(x * ea); }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 // -------------------------------------------------------------------------------------------------
 // conv_gemm: LDS-tiled implicit GEMM on v_mfma_f32_32x32x2_f32.
-//   workgroup tile: BN = 32*TN rows (output channels x phases)  x  BM = 256 time positions
-//   wave w: all BN rows x positions [64w, 64w+64)  -> TN x 2 accumulator tiles of 32x32
-//   K loop: for each block of 32 input channels: stage the halo tile Xs[32][XW] once (SnakeBeta
-//   applied on the way in), then for each tap stage Ws[32][BN] (double-buffered, next tap
-//   prefetched into registers during the MFMAs) and run 16 k-steps reading Xs at a shifted offset.
+//   workgroup: 8 waves; tile = BN (= 32*TN rows: output channels x phases) x 256 time positions;
+//   wave w: all BN rows x positions [32w, 32w+32) -> TN accumulator tiles of 32x32.
+//   K loop, 16 input channels per block "cb":
+//     * the activation halo tile Xs[16][XW] is double-buffered: the tile of cb+1 is fetched into
+//       registers before the MFMAs of cb start and committed to LDS (SnakeBeta applied once per
+//       element) after its last tap, so its HBM/L2 latency and its VALU work hide under the MFMAs;
+//     * per tap a weight tile Ws[16][BN] (double-buffered, next one prefetched into a register
+//       during the MFMAs); the taps of a causal conv re-read the SAME Xs at shifted offsets;
+//     * one barrier per (cb, tap).
+//   FUSE (residual units whose channels fit one tile): the accumulator H = conv7(snake(x)) becomes
+//   snake2(H + b1) in registers and is fed straight back as the B operand of the 1x1 conv (time
+//   stays on the lane; H's channel index is the k of the second product), then + b2 + x.
+//   (Measured on MI355X, G=32: staging X without the prefetch cost 11-13% of conv7 time and 26% of the
+//    2-tap transposed convs; weights straight from L2 instead of LDS were 15% slower.)
 // -------------------------------------------------------------------------------------------------
-template <int TN>
-__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs a, int HL, int XW, int tiles_per_unit,
-                                                            int n_tiles) {
+static constexpr int NWV = 8;                 // waves per workgroup
+static constexpr int NTH = NWV * 64;
+
+template <int TN, bool FUSE>
+__global__ __launch_bounds__(NTH, (FUSE && TN > 4) ? 2 : 4) void conv_gemm_kernel(ConvGemmArgs a, int HL, int XW, int tiles_per_unit,
+                                                                       int n_tiles) {
     constexpr int BN = TN * 32;
+    constexpr int WF4 = 4 * BN;                      // float4 per W tile [BK][BN]
+    constexpr int WPT = (WF4 + NTH - 1) / NTH;       // float4 per thread (1 for TN <= 4, 2 for TN = 6)
+    static_assert(WPT <= 2, "W staging registers");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *Xs = smem;                    // [BK][XW]
-    float *Ws = smem + BK * XW;          // [2][BK][BN]
+    const int xtile = BK * XW;
+    float *Ws = smem + 2 * xtile;                    // [2][BK][BN] after Xs[2][BK][XW]
 
     // XCD-aware remap (bijective): blocks that share an activation tile (same position tile,
     // different row tiles) get consecutive ids on one XCD, so the tile is fetched into one L2.
@@ -49,134 +108,220 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs a, int H
 
     const float *xu = a.x + (long)unit * a.x_us;
     const int ncb = (a.Cin + BK - 1) / BK;
-    const int CinP = ncb * BK;
+    const int CinP = ((a.Cin + 31) / 32) * 32;       // row count per tap of the packed weight tensor
     const int nstage = ncb * a.ntaps;
+    const int xw4 = XW >> 2;
 
-    f32x16 acc[TN][2];
+    f32x16 acc[TN];
 #pragma unroll
     for (int i = 0; i < TN; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+        for (int r = 0; r < 16; r++) acc[i][r] = 0.0f;
 
-    // W staging: tile [BK][BN] = 8*BN float4, 256 threads -> BN/32 = TN float4 each (named
-    // registers: an indexed float4 array here ends up in scratch)
-    float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f), w1 = w0, w2 = w0, w3 = w0;
-    const int wk0 = tid / (BN / 4), wc0 = (tid - wk0 * (BN / 4)) * 4;                    // idx = tid
-    const int wk1 = (tid + 256) / (BN / 4), wc1 = (tid + 256 - wk1 * (BN / 4)) * 4;      // idx = tid + 256
-    const int wk2 = (tid + 512) / (BN / 4), wc2 = (tid + 512 - wk2 * (BN / 4)) * 4;
-    const int wk3 = (tid + 768) / (BN / 4), wc3 = (tid + 768 - wk3 * (BN / 4)) * 4;
+    // ---- W staging through named registers
+    float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f), w1 = w0;
+    const int wk0 = tid / (BN / 4), wc0 = (tid - wk0 * (BN / 4)) * 4;
+    const int wk1 = (tid + NTH) / (BN / 4), wc1 = (tid + NTH - wk1 * (BN / 4)) * 4;
+    // tile = BK rows starting at wp_ (row stride ld_), columns n0..n0+BN
+#define W_LOAD_FROM(wp_, ld_)                                                                              \
+    {                                                                                                      \
+        if (WF4 >= NTH || tid < WF4) w0 = *reinterpret_cast<const float4 *>((wp_) + (long)wk0 * (ld_) + wc0); \
+        if constexpr (WPT > 1) if (WF4 >= 2 * NTH || tid + NTH < WF4) w1 = *reinterpret_cast<const float4 *>((wp_) + (long)wk1 * (ld_) + wc1); \
+    }
 #define W_LOAD(stage_)                                                                             \
     {                                                                                              \
         int cb_ = (stage_) / a.ntaps, tap_ = (stage_)-cb_ * a.ntaps;                               \
         const float *wp_ = a.w + ((long)tap_ * CinP + (long)cb_ * BK) * a.NP + n0;                 \
-        w0 = *reinterpret_cast<const float4 *>(wp_ + (long)wk0 * a.NP + wc0);                      \
-        if constexpr (TN > 1) w1 = *reinterpret_cast<const float4 *>(wp_ + (long)wk1 * a.NP + wc1); \
-        if constexpr (TN > 2) w2 = *reinterpret_cast<const float4 *>(wp_ + (long)wk2 * a.NP + wc2); \
-        if constexpr (TN > 3) w3 = *reinterpret_cast<const float4 *>(wp_ + (long)wk3 * a.NP + wc3); \
+        W_LOAD_FROM(wp_, a.NP)                                                                     \
     }
 #define W_STORE(buf_)                                                                              \
     {                                                                                              \
         float *ws_ = Ws + (buf_) * (BK * BN) + tid * 4;                                            \
-        *reinterpret_cast<float4 *>(ws_) = w0;                                                     \
-        if constexpr (TN > 1) *reinterpret_cast<float4 *>(ws_ + 1024) = w1;                        \
-        if constexpr (TN > 2) *reinterpret_cast<float4 *>(ws_ + 2048) = w2;                        \
-        if constexpr (TN > 3) *reinterpret_cast<float4 *>(ws_ + 3072) = w3;                        \
+        if (WF4 >= NTH || tid < WF4) *reinterpret_cast<float4 *>(ws_) = w0;                        \
+        if constexpr (WPT > 1) if (WF4 >= 2 * NTH || tid + NTH < WF4) *reinterpret_cast<float4 *>(ws_ + 4 * NTH) = w1; \
     }
-    // X staging: rows k = wave, wave+4, ...; lanes sweep the row in float4 steps.
-    auto x_stage = [&](int cb) {
-        const int xw4 = XW >> 2;
-        for (int k = wave; k < BK; k += 4) {
-            int ci = cb * BK + k;
-            bool cok = ci < a.Cin;
-            const float *xr = xu + (long)ci * a.x_cs;
-            float sa = 0.0f, sib = 0.0f;
-            if (a.sn_a && cok) { sa = a.sn_a[ci]; sib = a.sn_ib[ci]; }
-            for (int c4 = lane; c4 < xw4; c4 += 64) {
-                int pos = m0 - HL + c4 * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (cok) {
-                    if (pos >= 0 && pos + 4 <= a.Lin) {
-                        v = *reinterpret_cast<const float4 *>(xr + pos);
-                    } else {
-                        if (pos + 0 >= 0 && pos + 0 < a.Lin) v.x = xr[pos + 0];
-                        if (pos + 1 >= 0 && pos + 1 < a.Lin) v.y = xr[pos + 1];
-                        if (pos + 2 >= 0 && pos + 2 < a.Lin) v.z = xr[pos + 2];
-                        if (pos + 3 >= 0 && pos + 3 < a.Lin) v.w = xr[pos + 3];
-                    }
-                    if (a.sn_a) {   // SnakeBeta: x + 1/(e^beta+1e-9) * sin(x e^alpha)^2 ; snake(0) == 0
-                        float s;
-                        s = sinf(v.x * sa); v.x = v.x + sib * (s * s);
-                        s = sinf(v.y * sa); v.y = v.y + sib * (s * s);
-                        s = sinf(v.z * sa); v.z = v.z + sib * (s * s);
-                        s = sinf(v.w * sa); v.w = v.w + sib * (s * s);
-                    }
-                }
-                *reinterpret_cast<float4 *>(Xs + k * XW + c4 * 4) = v;
-            }
-        }
-    };
 
-    W_LOAD(0);
-    W_STORE(0);
-    for (int st = 0; st < nstage; st++) {
-        int cb = st / a.ntaps, tap = st - cb * a.ntaps;
-        if (tap == 0) {
-            __syncthreads();          // every wave is done reading the previous Xs
-            x_stage(cb);
-        }
-        if (st + 1 < nstage) W_LOAD(st + 1);
-        __syncthreads();              // Ws[st&1] and Xs are visible
-        {
-            const float *ws = Ws + (st & 1) * (BK * BN) + l31;
-            const float *xs = Xs + wave * 64 + l31 + HL + a.shift0 + tap * a.shift_step;
-#pragma unroll
-            for (int kk = 0; kk < BK / 2; kk++) {
-                int k = 2 * kk + h;
-                float av[TN], bv[2];
-#pragma unroll
-                for (int i = 0; i < TN; i++) av[i] = ws[k * BN + i * 32];
-#pragma unroll
-                for (int j = 0; j < 2; j++) bv[j] = xs[k * XW + j * 32];
-#pragma unroll
-                for (int i = 0; i < TN; i++)
-#pragma unroll
-                    for (int j = 0; j < 2; j++)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    // ---- X tile: fetch (global -> 3 float4 registers per thread) and commit (SnakeBeta, -> LDS)
+    float4 xr0, xr1, xr2;
+    int xk0, xk1, xk2, xc0, xc1, xc2;                // (row, float4 column) of this thread's pieces
+    {
+        int i0 = tid, i1 = tid + NTH, i2 = tid + 2 * NTH;
+        xk0 = i0 / xw4; xc0 = i0 - xk0 * xw4;
+        xk1 = i1 / xw4; xc1 = i1 - xk1 * xw4;
+        xk2 = i2 / xw4; xc2 = i2 - xk2 * xw4;
+    }
+    auto x_fetch1 = [&](int cb, int k, int c4) -> float4 {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        int ci = cb * BK + k;
+        if (k < BK && ci < a.Cin) {
+            const float *xr = xu + (long)ci * a.x_cs;
+            int pos = m0 - HL + c4 * 4;
+            if (pos >= 0 && pos + 4 <= a.Lin) {
+                v = *reinterpret_cast<const float4 *>(xr + pos);
+            } else {
+                if (pos + 0 >= 0 && pos + 0 < a.Lin) v.x = xr[pos + 0];
+                if (pos + 1 >= 0 && pos + 1 < a.Lin) v.y = xr[pos + 1];
+                if (pos + 2 >= 0 && pos + 2 < a.Lin) v.z = xr[pos + 2];
+                if (pos + 3 >= 0 && pos + 3 < a.Lin) v.w = xr[pos + 3];
             }
         }
-        if (st + 1 < nstage) W_STORE((st + 1) & 1);
+        return v;
+    };
+    // SnakeBeta parameters of each piece's channel travel with the prefetch (loading them at commit
+    // time would expose an L2 round trip per channel block)
+    float2 xp0 = make_float2(0.f, 0.f), xp1 = xp0, xp2 = xp0;
+    auto p_fetch1 = [&](int cb, int k) -> float2 {
+        int ci = cb * BK + k;
+        if (a.sn_a && k < BK && ci < a.Cin) return make_float2(a.sn_a[ci], a.sn_ib[ci]);
+        return make_float2(0.f, 0.f);
+    };
+    auto x_commit1 = [&](int buf, int k, int c4, float4 v, float2 sp) {
+        if (k >= BK) return;
+        if (a.sn_a) {   // SnakeBeta: x + 1/(e^beta+1e-9) * sin(x e^alpha)^2 ; snake(0) == 0 keeps the zero padding
+            v.x = snake_beta(v.x, sp.x, sp.y);
+            v.y = snake_beta(v.y, sp.x, sp.y);
+            v.z = snake_beta(v.z, sp.x, sp.y);
+            v.w = snake_beta(v.w, sp.x, sp.y);
+        }
+        *reinterpret_cast<float4 *>(smem + buf * xtile + k * XW + c4 * 4) = v;
+    };
+#define X_FETCH(cb_) { xr0 = x_fetch1(cb_, xk0, xc0); xr1 = x_fetch1(cb_, xk1, xc1); xr2 = x_fetch1(cb_, xk2, xc2); \
+                       xp0 = p_fetch1(cb_, xk0); xp1 = p_fetch1(cb_, xk1); xp2 = p_fetch1(cb_, xk2); }
+#define X_COMMIT(cb_, buf_) { x_commit1(buf_, xk0, xc0, xr0, xp0); x_commit1(buf_, xk1, xc1, xr1, xp1); x_commit1(buf_, xk2, xc2, xr2, xp2); }
+
+    X_FETCH(0)
+    W_LOAD(0);
+    X_COMMIT(0, 0)
+    W_STORE(0);
+    for (int cb = 0; cb < ncb; cb++) {
+        const bool xnext = cb + 1 < ncb && !(a.dbg & 1);
+        if (xnext) X_FETCH(cb + 1)
+        for (int tap = 0; tap < a.ntaps; tap++) {
+            const int st = cb * a.ntaps + tap;
+            if (st + 1 < nstage) W_LOAD(st + 1);
+            __syncthreads();              // Ws[st&1] (and, at tap 0, the committed Xs[cb&1]) are visible
+            {
+                const float *ws = Ws + (st & 1) * (BK * BN) + l31;
+                const float *xs = smem + (cb & 1) * xtile + wave * 32 + l31 + HL + a.shift0 + tap * a.shift_step;
+#pragma unroll
+                for (int kk = 0; kk < BK / 2; kk++) {
+                    int k = 2 * kk + h;
+                    float av[TN];
+#pragma unroll
+                    for (int i = 0; i < TN; i++) av[i] = ws[k * BN + i * 32];
+                    float bv = xs[k * XW];
+#pragma unroll
+                    for (int i = 0; i < TN; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv, acc[i], 0, 0, 0);
+                }
+            }
+            if (st + 1 < nstage) W_STORE((st + 1) & 1);
+        }
+        // Xs[(cb+1)&1] was last read during cb-1; every wave has passed a later barrier since
+        if (xnext) X_COMMIT(cb + 1, (cb + 1) & 1)
+    }
+#undef X_FETCH
+#undef X_COMMIT
+
+    if constexpr (FUSE) {
+        // H = snake2(acc + b1), in place.  Register r of tile i is channel i*32 + (r&3) + 8*(r>>2) + 4*h.
+        // bias / snake vectors are zero-padded by the loader, so padded rows stay exactly 0.
+#pragma unroll
+        for (int i = 0; i < TN; i++) {
+            const float *b1p = launder_after(a.bias, acc[i][15]), *s2a = launder_after(a.sn2_a, acc[i][15]),
+                        *s2b = launder_after(a.sn2_ib, acc[i][15]);
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                int n = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                acc[i][r] = snake_beta(acc[i][r] + b1p[n], s2a[n], s2b[n]);
+                // four activations in flight at a time: unbounded, the scheduler interleaves all 16*TN
+                // polynomial chains and their temporaries spill
+                if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // second product, ONE 32-row output tile at a time (16 accumulator registers instead of 16*TN, so
+        // the C=96 unit still runs four waves per SIMD); its weights go through the same Ws double
+        // buffer, as [16 k rows][32 output rows] stages (8 registers of H each)
+        float *yu = a.y + (long)unit * a.y_us;
+        const int m = m0 + wave * 32 + l31;
+        // W2 stage (s2, o): rows [16*s2, 16*s2+16) x columns [32*o, 32*o+32) of the packed [NP][NP] tensor:
+        // 128 float4, loaded by the first 128 threads
+        const int w2k = tid >> 3, w2c = (tid & 7) * 4;
+        float4 w2r = make_float4(0.f, 0.f, 0.f, 0.f);
+#define W2_LOAD(s2_, o_) { if (tid < 128) w2r = *reinterpret_cast<const float4 *>(a.w2 + (long)((s2_) * BK + w2k) * a.NP + (o_) * 32 + w2c); }
+#define W2_STORE(buf_) { if (tid < 128) *reinterpret_cast<float4 *>(Ws + (buf_) * (BK * 32) + w2k * 32 + w2c) = w2r; }
+        W2_LOAD(0, 0)
+        __syncthreads();                          // every wave is done with the main loop's Ws
+        W2_STORE(0)
+        int buf = 0;
+#pragma unroll
+        for (int o = 0; o < TN; o++) {
+            f32x16 acc2;
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc2[r] = 0.0f;
+#pragma unroll
+            for (int s2 = 0; s2 < 2 * TN; s2++) {
+                const int i = s2 >> 1, half = s2 & 1;
+                const bool last = (o == TN - 1) && (s2 == 2 * TN - 1);
+                if (!last) {
+                    const int s2n = s2 + 1 < 2 * TN ? s2 + 1 : 0, on = s2 + 1 < 2 * TN ? o : o + 1;
+                    W2_LOAD(s2n, on)
+                }
+                __syncthreads();
+                const float *ws = Ws + buf * (BK * 32) + l31;
+#pragma unroll
+                for (int rr = 0; rr < 8; rr++) {
+                    const int r = half * 8 + rr;
+                    int k = (rr & 3) + 8 * (rr >> 2) + 4 * h;   // row inside this 16-row stage of the k this lane half holds in register r
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ws[k * 32], acc[i][r], acc2, 0, 0, 0);
+                }
+                buf ^= 1;
+                if (!last) W2_STORE(buf)
+            }
+            // + b2 + residual x, store this 32-row tile
+            const float *b2p = launder_after(a.bias2, acc2[15]);
+            const float *rup = launder_after(a.res, acc2[15]) + (long)unit * a.y_us;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                int n = o * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (n >= a.N || m >= a.M) continue;
+                long oo = (long)n * a.y_cs + m;
+                yu[oo] = rup[oo] + (acc2[r] + b2p[n]);
+            }
+        }
+#undef W2_LOAD
+#undef W2_STORE
+        return;
     }
 
     // epilogue: bias, activation, per-channel scale, residual, store (time on the lane: coalesced)
     float *yu = a.y + (long)unit * a.y_us;
-    const float *ru = a.res ? a.res + (long)unit * a.y_us : nullptr;
+    const float *ru0 = launder_after(a.res, acc[TN - 1][15]);
+    const float *ru = ru0 ? ru0 + (long)unit * a.y_us : nullptr;
+    const float *bp = launder_after(a.bias, acc[TN - 1][15]), *scp = launder_after(a.rscale, acc[TN - 1][15]);
+    const int m = m0 + wave * 32 + l31;
 #pragma unroll
     for (int i = 0; i < TN; i++) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             int n = n0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (n >= a.N) continue;
+            if (n >= a.N || m >= a.M) continue;
             int co = n, ph = 0;
             if (a.S > 1) { co = n / a.S; ph = n - co * a.S; }
-            float bb = a.bias ? a.bias[co] : 0.0f;
-            float sc = a.rscale ? a.rscale[co] : 1.0f;
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                int m = m0 + wave * 64 + j * 32 + l31;
-                if (m >= a.M) continue;
-                float v = acc[i][j][r] + bb;
-                if (a.act == ACT_GELU) v = gelu_erf(v);
-                if (a.rscale) v = v * sc;
-                long o = (long)co * a.y_cs + (long)m * a.S + ph;
-                if (ru) v = ru[o] + v;
-                if (a.act == ACT_CLAMP1) v = fminf(fmaxf(v, -1.0f), 1.0f);
-                yu[o] = v;
-            }
+            float bb = bp ? bp[co] : 0.0f;
+            float sc = scp ? scp[co] : 1.0f;
+            float v = acc[i][r] + bb;
+            if (a.act == ACT_GELU) v = gelu_erf(v);
+            if (scp) v = v * sc;
+            long o = (long)co * a.y_cs + (long)m * a.S + ph;
+            if (ru) v = ru[o] + v;
+            if (a.act == ACT_CLAMP1) v = fminf(fmaxf(v, -1.0f), 1.0f);
+            yu[o] = v;
         }
     }
 }
+#undef W_LOAD_FROM
+#undef W_LOAD
+#undef W_STORE
 
 static void conv_gemm_geometry(const ConvGemmArgs &a, int &HL, int &XW) {
     int smin = a.shift0, smax = a.shift0;
@@ -188,49 +333,95 @@ static void conv_gemm_geometry(const ConvGemmArgs &a, int &HL, int &XW) {
     XW = BM + HL + ((hr + 3) & ~3);
 }
 
+// Tile height actually launched: the packed TN, lowered for small grids (more workgroups), or
+// NP/32 for the fused residual unit (one tile must hold every channel).
+static int conv_gemm_launch_tn(const ConvGemmArgs &a) {
+    if (a.w2) return a.NP / 32;
+    int tiles_m = ((a.M + BM - 1) / BM) * a.units;
+    int tn = a.TN;
+    while (tn > 1 && (long)tiles_m * (a.NP / (32 * tn)) < 512) {
+        int t2 = tn == 4 ? 2 : 1;
+        if (a.NP % (32 * t2)) break;
+        tn = t2;
+    }
+    return tn;
+}
+
+const char *conv_gemm_kernel_name(const ConvGemmArgs &a) {
+    static char names[2][8][40];
+    int tn = conv_gemm_launch_tn(a);
+    int fuse = a.w2 ? 1 : 0;
+    char *n = names[fuse][tn & 7];
+    if (!n[0]) snprintf(n, 40, "conv_gemm_kernel<%d,%s>", tn, fuse ? "true" : "false");
+    return n;
+}
+
 size_t conv_gemm_lds_bytes(const ConvGemmArgs &a) {
     int HL, XW;
     conv_gemm_geometry(a, HL, XW);
-    return sizeof(float) * ((size_t)BK * XW + 2 * (size_t)BK * 32 * a.TN);
+    return sizeof(float) * (2 * (size_t)BK * XW + 2 * (size_t)BK * 32 * conv_gemm_launch_tn(a));
 }
 
-hipError_t launch_conv_gemm(const ConvGemmArgs &a, hipStream_t s) {
+template <int TN, bool FUSE>
+static hipError_t conv_gemm_launch_one(const ConvGemmArgs &a, int HL, int XW, int tiles_per_unit, int n_tiles,
+                                       long grid, size_t lds, hipStream_t s) {
+    static bool done[64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64 && !done[dev]) {   // dynamic LDS above 64 KiB must be enabled per function and device
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_gemm_kernel<TN, FUSE>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        done[dev] = true;
+    }
+    hipLaunchKernelGGL((conv_gemm_kernel<TN, FUSE>), dim3((unsigned)grid), dim3(NTH), lds, s, a, HL, XW, tiles_per_unit,
+                       n_tiles);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv_gemm(const ConvGemmArgs &a_in, hipStream_t s) {
+    ConvGemmArgs a = a_in;
+    {   // timing-only ablation switch (HIPVOC_DBG bit0: stage the activation tile only once).  Results are
+        // WRONG with it set; never set in production.
+        static int dbg = -1;
+        if (dbg < 0) { const char *e = getenv("HIPVOC_DBG"); dbg = e ? atoi(e) : 0; }
+        a.dbg = dbg;
+    }
     int HL, XW;
     conv_gemm_geometry(a, HL, XW);
     if (a.M <= 0 || a.units <= 0) return hipSuccess;
     // host-side shape checks: what the kernel's vector accesses assume
     if ((a.x_cs & 3) || (a.x_us & 3) || (a.NP % (32 * a.TN)) || a.NP < a.N || a.TN < 1 || a.TN > 4 ||
-        ((uintptr_t)a.x & 15) || ((uintptr_t)a.w & 15) || a.ntaps < 1 || a.S < 1)
+        ((uintptr_t)a.x & 15) || ((uintptr_t)a.w & 15) || a.ntaps < 1 || a.S < 1 || BK * (XW / 4) > 3 * NTH)
+        return hipErrorInvalidValue;
+    const int tn = conv_gemm_launch_tn(a);
+    if (a.w2 && (a.S != 1 || a.NP != 32 * tn || (a.N + 31) / 32 != tn || tn == 5 || tn > 6 || !a.res || !a.sn2_a ||
+                 !a.sn2_ib || !a.bias || !a.bias2 || ((uintptr_t)a.w2 & 15)))
         return hipErrorInvalidValue;
     int tiles_per_unit = (a.M + BM - 1) / BM;
-    int n_tiles = a.NP / (32 * a.TN);
+    int n_tiles = a.NP / (32 * tn);
     long grid = (long)tiles_per_unit * a.units * n_tiles;
     if (grid > 0x7fffffffL) return hipErrorInvalidValue;
     size_t lds = conv_gemm_lds_bytes(a);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    {   // dynamic LDS above 64 KiB must be enabled per function and device
-        static bool done[64] = {};
-        int dev = 0;
-        hipError_t e = hipGetDevice(&dev);
-        if (e != hipSuccess) return e;
-        if (dev >= 0 && dev < 64 && !done[dev]) {
-            const int cap = 160 * 1024;
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_gemm_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_gemm_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_gemm_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_gemm_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-            if (e != hipSuccess) return e;
-            done[dev] = true;
+#define GO(TN_, F_) return conv_gemm_launch_one<TN_, F_>(a, HL, XW, tiles_per_unit, n_tiles, grid, lds, s)
+    if (a.w2) {
+        switch (tn) {
+            case 1: GO(1, true);
+            case 2: GO(2, true);
+            case 3: GO(3, true);
+            case 4: GO(4, true);
+            default: GO(6, true);
         }
     }
-    dim3 g((unsigned)grid), b(256);
-    switch (a.TN) {
-        case 1: hipLaunchKernelGGL(conv_gemm_kernel<1>, g, b, lds, s, a, HL, XW, tiles_per_unit, n_tiles); break;
-        case 2: hipLaunchKernelGGL(conv_gemm_kernel<2>, g, b, lds, s, a, HL, XW, tiles_per_unit, n_tiles); break;
-        case 3: hipLaunchKernelGGL(conv_gemm_kernel<3>, g, b, lds, s, a, HL, XW, tiles_per_unit, n_tiles); break;
-        default: hipLaunchKernelGGL(conv_gemm_kernel<4>, g, b, lds, s, a, HL, XW, tiles_per_unit, n_tiles); break;
+    switch (tn) {
+        case 1: GO(1, false);
+        case 2: GO(2, false);
+        case 3: GO(3, false);
+        default: GO(4, false);
     }
-    return hipGetLastError();
+#undef GO
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -277,24 +468,34 @@ hipError_t launch_rvq(const RvqArgs &a, hipStream_t s) {
 }
 
 // -------------------------------------------------------------------------------------------------
-// RMSNorm over channels; one thread per position, lanes on consecutive positions.
+// RMSNorm over channels of x[C][P].  Workgroup = 32 positions x 8 channel slices: lanes 0-31 of a
+// wave walk consecutive positions (128-B rows), slices are reduced through LDS in a fixed order.
 // -------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const float *x, float *y, const float *w, int C, long P,
                                                        float eps) {
-    long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= P) return;
+    __shared__ float red[8][32];
+    int lp = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    long p = (long)blockIdx.x * 32 + lp;
+    bool ok = p < P;
     float ss = 0.0f;
-    for (int c = 0; c < C; c++) {
-        float v = x[(long)c * P + p];
-        ss += v * v;
-    }
-    float r = 1.0f / sqrtf(ss / (float)C + eps);
-    for (int c = 0; c < C; c++) y[(long)c * P + p] = w[c] * (x[(long)c * P + p] * r);
+    if (ok)
+        for (int c = sl; c < C; c += 8) {
+            float v = x[(long)c * P + p];
+            ss += v * v;
+        }
+    red[sl][lp] = ss;
+    __syncthreads();
+    float tot = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) tot += red[i][lp];
+    float r = 1.0f / sqrtf(tot / (float)C + eps);
+    if (ok)
+        for (int c = sl; c < C; c += 8) y[(long)c * P + p] = w[c] * (x[(long)c * P + p] * r);
 }
 
 hipError_t launch_rmsnorm(const float *x, float *y, const float *w, int C, long P, float eps, hipStream_t s) {
     if (P <= 0) return hipSuccess;
-    hipLaunchKernelGGL(rmsnorm_kernel, dim3((unsigned)((P + 63) / 64)), dim3(64), 0, s, x, y, w, C, P, eps);
+    hipLaunchKernelGGL(rmsnorm_kernel, dim3((unsigned)((P + 31) / 32)), dim3(256), 0, s, x, y, w, C, P, eps);
     return hipGetLastError();
 }
 
@@ -436,46 +637,125 @@ hipError_t launch_swiglu(float *g, const float *u, long n, hipStream_t s) {
 }
 
 // -------------------------------------------------------------------------------------------------
-// ConvNeXt front half: depthwise causal conv (k taps, left pad k-1) + LayerNorm over channels.
-// One thread per (unit, position); lanes on consecutive positions.  y doubles as scratch for the
-// conv output between the passes (each thread re-reads only what it wrote).
+// ConvNeXt front half: depthwise causal conv (K taps, left pad K-1) + LayerNorm over channels
+// (two-pass variance).  Workgroup = 32 positions x 8 channel slices; y holds the conv output between
+// the passes (each thread re-reads only what it wrote itself).
 // -------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void dwconv_ln_kernel(const float *x, float *y, const float *dw_w,
-                                                        const float *dw_b, const float *ln_w, const float *ln_b,
-                                                        int C, int K, int G, int L, int Lp, float eps) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void dwconv_ln_kernel(const float *x, float *y, const float *dw_w,
+                                                         const float *dw_b, const float *ln_w, const float *ln_b,
+                                                         int C, int K, int G, int L, int Lp, float eps) {
+    __shared__ float red[8][32];
+    int lp = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    int t = blockIdx.x * 32 + lp;
     int u = blockIdx.y;
-    if (t >= L) return;
+    bool ok = t < L;
     long cs = (long)G * Lp, base = (long)u * Lp + t;
-    float mean = 0.0f;
-    for (int c = 0; c < C; c++) {
-        float acc = dw_b[c];
-        const float *xr = x + (long)c * cs + (long)u * Lp;
-        for (int j = 0; j < K; j++) {
-            int sidx = t - (K - 1 - j);
-            if (sidx >= 0) acc += dw_w[c * K + j] * xr[sidx];
+    float sum = 0.0f;
+    if (ok)
+        for (int c = sl; c < C; c += 8) {
+            float acc = dw_b[c];
+            const float *xr = x + (long)c * cs + (long)u * Lp;
+            for (int j = 0; j < K; j++) {
+                int sidx = t - (K - 1 - j);
+                if (sidx >= 0) acc += dw_w[c * K + j] * xr[sidx];
+            }
+            y[(long)c * cs + base] = acc;
+            sum += acc;
         }
-        y[(long)c * cs + base] = acc;
-        mean += acc;
-    }
+    red[sl][lp] = sum;
+    __syncthreads();
+    float mean = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) mean += red[i][lp];
     mean /= (float)C;
+    __syncthreads();
     float var = 0.0f;
-    for (int c = 0; c < C; c++) {
-        float d = y[(long)c * cs + base] - mean;
-        var += d * d;
-    }
-    float r = 1.0f / sqrtf(var / (float)C + eps);
-    for (int c = 0; c < C; c++) {
-        float v = y[(long)c * cs + base];
-        y[(long)c * cs + base] = (v - mean) * r * ln_w[c] + ln_b[c];
-    }
+    if (ok)
+        for (int c = sl; c < C; c += 8) {
+            float d = y[(long)c * cs + base] - mean;
+            var += d * d;
+        }
+    red[sl][lp] = var;
+    __syncthreads();
+    float vt = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) vt += red[i][lp];
+    float r = 1.0f / sqrtf(vt / (float)C + eps);
+    if (ok)
+        for (int c = sl; c < C; c += 8) {
+            float v = y[(long)c * cs + base];
+            y[(long)c * cs + base] = (v - mean) * r * ln_w[c] + ln_b[c];
+        }
 }
 
 hipError_t launch_dwconv_ln(const float *x, float *y, const float *dw_w, const float *dw_b, const float *ln_w,
                             const float *ln_b, int C, int K, int G, int L, int Lp, float eps, hipStream_t s) {
     if (G <= 0 || L <= 0) return hipSuccess;
-    hipLaunchKernelGGL(dwconv_ln_kernel, dim3((L + 63) / 64, G), dim3(64), 0, s, x, y, dw_w, dw_b, ln_w, ln_b, C, K,
+    hipLaunchKernelGGL(dwconv_ln_kernel, dim3((L + 31) / 32, G), dim3(256), 0, s, x, y, dw_w, dw_b, ln_w, ln_b, C, K,
                        G, L, Lp, eps);
+    return hipGetLastError();
+}
+
+// -------------------------------------------------------------------------------------------------
+// Final stage: SnakeBeta -> causal conv C -> 1 channel (K <= 9 taps) -> clamp[-1,1].
+// HBM-bound (reads C floats per output sample): no LDS, every thread produces 4 consecutive samples
+// and recomputes the K-1 halo activations it needs from aligned float4 loads (neighbours' loads hit L1/L2).
+// -------------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(256) void final_conv_kernel(const float *x, float *out, const float *w /*[C][K]*/,
+                                                          const float *bias, const float *sn_a, const float *sn_ib,
+                                                          int C, int G, int L, int Lp, long out_stride,
+                                                          int vec_store) {
+    int t = (blockIdx.x * 256 + threadIdx.x) * 4;
+    int u = blockIdx.y;
+    if (t >= L) return;
+    long cs = (long)G * Lp;
+    const float *xu = x + (long)u * Lp;
+    float acc[4];
+    float b0 = bias ? bias[0] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) acc[i] = b0;
+    for (int c = 0; c < C; c++) {
+        const float *xr = xu + (long)c * cs;
+        float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 v0 = t >= 8 ? *reinterpret_cast<const float4 *>(xr + t - 8) : z;
+        float4 v1 = t >= 4 ? *reinterpret_cast<const float4 *>(xr + t - 4) : z;
+        float4 v2 = *reinterpret_cast<const float4 *>(xr + t);
+        float sa = sn_a[c], sib = sn_ib[c];
+        float sv[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            int pos = t - 8 + i;
+            float s = snake_beta(sv[i], sa, sib);
+            sv[i] = (pos >= 0 && pos < L) ? s : 0.0f;       // zero padding applies to the activation output
+        }
+#pragma unroll
+        for (int j = 0; j < K; j++) {
+            float wv = w[c * K + j];
+#pragma unroll
+            for (int i = 0; i < 4; i++) acc[i] += wv * sv[8 + i - (K - 1) + j];   // sample t+i reads activation t+i-(K-1-j)
+        }
+    }
+    float *o = out + (long)u * out_stride + t;
+#pragma unroll
+    for (int i = 0; i < 4; i++) acc[i] = fminf(fmaxf(acc[i], -1.0f), 1.0f);
+    if (vec_store && t + 4 <= L) {
+        *reinterpret_cast<float4 *>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (t + i < L) o[i] = acc[i];
+    }
+}
+
+hipError_t launch_final_conv(const float *x, float *out, const float *w, const float *bias, const float *sn_a,
+                             const float *sn_ib, int C, int K, int G, int L, int Lp, long out_stride, hipStream_t s) {
+    if (G <= 0 || L <= 0) return hipSuccess;
+    if (K != 7 || (Lp & 3) || ((uintptr_t)x & 15)) return hipErrorInvalidValue;
+    int vec = ((out_stride & 3) == 0 && ((uintptr_t)out & 15) == 0) ? 1 : 0;
+    int nthr = (L + 3) / 4;
+    hipLaunchKernelGGL(final_conv_kernel<7>, dim3((nthr + 255) / 256, G), dim3(256), 0, s, x, out, w, bias, sn_a, sn_ib, C,
+                       G, L, Lp, out_stride, vec);
     return hipGetLastError();
 }
 
