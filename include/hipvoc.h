@@ -98,7 +98,7 @@ int hipvoc_sync(void *h);
 /* The hipStream_t the handle launches on (for hipEvent timing by the caller). */
 void *hipvoc_stream(void *h);
 
-/* Units decoded per pass (workspace is sized for this many; default 32, env HIPVOC_GROUP). */
+/* Units decoded per pass (workspace is sized for this many; default 64, env HIPVOC_GROUP). */
 int hipvoc_group_units(void *h);
 
 /* Algorithmic work of one unit, recomputed from the loaded tensor shapes:

@@ -90,9 +90,10 @@ struct Plan {
 struct Ctx {
     int device = 0;
     int unit_frames = 64;
-    int group = 32;
+    int group = 64;
     bool profile = false;
     bool fuse_res = true;
+    bool post_snake = true;
     hipStream_t stream = nullptr;
     std::string err;
     std::vector<void *> dev_allocs;
@@ -501,9 +502,10 @@ struct PlanBuilder {
 
     // x[Cin][G][Lpi] -> y[N/S][G][Lpo]
     void gemm(const char *name, const Gemm &g, const float *x, int Lin, int Lpi, float *y, int Lpo, const Snake *sn,
-              const float *res, const float *rscale, int act) {
+              const float *res, const float *rscale, int act, const Snake *post = nullptr) {
         ConvGemmArgs a{};
         a.x = x; a.y = y; a.w = g.w; a.bias = g.bias; a.res = res; a.rscale = rscale;
+        a.psn_a = post ? post->ea : nullptr; a.psn_ib = post ? post->ib : nullptr;
         a.sn_a = sn ? sn->ea : nullptr; a.sn_ib = sn ? sn->ib : nullptr;
         a.Cin = g.Cin; a.N = g.N; a.NP = g.NP; a.TN = g.TN;
         a.ntaps = g.ntaps; a.shift0 = g.shift0; a.shift_step = g.step; a.S = g.S; a.act = act;
@@ -526,8 +528,9 @@ struct PlanBuilder {
                c1.NP / 32 <= 6 && c1.NP / 32 != 5 && (c1.N + 31) / 32 == c1.NP / 32 && c1.bias && c2.bias;
     }
     void res_unit_fused(const char *name, const Gemm &c1, const Gemm &c2, const Snake &s1, const Snake &s2, const float *x,
-                        int L, int Lp, float *y) {
+                        int L, int Lp, float *y, const Snake *post) {
         ConvGemmArgs a{};
+        a.psn_a = post ? post->ea : nullptr; a.psn_ib = post ? post->ib : nullptr;
         a.x = x; a.y = y; a.w = c1.w; a.bias = c1.bias; a.res = x; a.sn_a = s1.ea; a.sn_ib = s1.ib;
         a.w2 = c2.w; a.bias2 = c2.bias; a.sn2_a = s2.ea; a.sn2_ib = s2.ib;
         a.Cin = c1.Cin; a.N = c1.N; a.NP = c1.NP; a.TN = c1.TN;
@@ -538,8 +541,8 @@ struct PlanBuilder {
     }
 };
 
-static Plan *get_plan(Ctx *c, int G, int T) {
-    auto key = std::make_pair(G, T);
+static Plan *get_plan(Ctx *c, int G, int T, bool debug = false) {
+    auto key = std::make_pair(debug ? -G : G, T);
     auto it = c->plans.find(key);
     if (it != c->plans.end()) return it->second.get();
     std::unique_ptr<Plan> plan(new Plan);
@@ -647,8 +650,14 @@ static Plan *get_plan(Ctx *c, int G, int T) {
         b.gemm("pwconv2", u.pw2, t2, L, Lp, cur, Lp, nullptr, cur, u.gamma, ACT_NONE);
         b.mark(st++, cur, C, L, Lp);
     }
+    // The SnakeBeta that opens decoder block k+1 is applied by the PRODUCER of its input (decoder[0] /
+    // the last residual unit of block k), once per element, instead of in the trans-conv's prologue once
+    // per row tile (up to 48x for block 0).  Debug plans (stage taps want the raw tensors) keep it in the
+    // consumer.
+    const bool post_snake = !debug && c->post_snake;
     // g5
-    b.gemm("dec0_conv7", c->dec0, cur, L, Lp, t1, Lp, nullptr, nullptr, nullptr, ACT_NONE);
+    b.gemm("dec0_conv7", c->dec0, cur, L, Lp, t1, Lp, nullptr, nullptr, nullptr, ACT_NONE,
+           post_snake && !c->blocks.empty() ? &c->blocks[0].s : nullptr);
     std::swap(cur, t1);
     C = c->dec_dim;
     b.mark(st++, cur, C, L, Lp);
@@ -662,18 +671,19 @@ static Plan *get_plan(Ctx *c, int G, int T) {
         int r = c->rates[bi];
         int L2 = (L - 1) * r, Lp2 = rup(L2, 4);
         size_t ni = std::min<size_t>(bi, 4);
-        b.gemm(tc_names[ni], blk.tc, cur, L, Lp, t1, Lp2, &blk.s, nullptr, nullptr, ACT_NONE);
+        b.gemm(tc_names[ni], blk.tc, cur, L, Lp, t1, Lp2, post_snake ? nullptr : &blk.s, nullptr, nullptr, ACT_NONE);
         std::swap(cur, t1);
         L = L2; Lp = Lp2; C = blk.tc.N / r;
         b.mark(st++, cur, C, L, Lp);
         for (int u = 0; u < 3; u++) {
             const Ctx::Res &ru = blk.res[u];
+            const Snake *post = (post_snake && u == 2 && bi + 1 < c->blocks.size()) ? &c->blocks[bi + 1].s : nullptr;
             if (c->fuse_res && PlanBuilder::can_fuse(ru.c1, ru.c2)) {
-                b.res_unit_fused(ru_names[ni], ru.c1, ru.c2, ru.s1, ru.s2, cur, L, Lp, t1);
+                b.res_unit_fused(ru_names[ni], ru.c1, ru.c2, ru.s1, ru.s2, cur, L, Lp, t1, post);
                 std::swap(cur, t1);
             } else {
                 b.gemm(c7_names[ni], ru.c1, cur, L, Lp, t1, Lp, &ru.s1, nullptr, nullptr, ACT_NONE);
-                b.gemm(c1_names[ni], ru.c2, t1, L, Lp, cur, Lp, &ru.s2, cur, nullptr, ACT_NONE);
+                b.gemm(c1_names[ni], ru.c2, t1, L, Lp, cur, Lp, &ru.s2, cur, nullptr, ACT_NONE, post);
             }
             b.mark(st++, cur, C, L, Lp);
         }
@@ -864,9 +874,10 @@ void *hipvoc_load(const char *weights_path, int device_id, int dtype, int unit_f
     std::unique_ptr<Ctx> c(new Ctx);
     c->device = device_id;
     c->unit_frames = unit_frames;
-    if (const char *g = getenv("HIPVOC_GROUP")) c->group = std::max(1, std::min(64, atoi(g)));
+    if (const char *g = getenv("HIPVOC_GROUP")) c->group = std::max(1, std::min(256, atoi(g)));
     if (const char *pf = getenv("HIPVOC_PROFILE")) c->profile = atoi(pf) != 0;
     if (const char *fz = getenv("HIPVOC_FUSE")) c->fuse_res = atoi(fz) != 0;
+    if (const char *ps = getenv("HIPVOC_POST_SNAKE")) c->post_snake = atoi(ps) != 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
     std::string err;
     if (!load_model(c.get(), weights_path, err)) return fail(err);
@@ -1026,7 +1037,7 @@ int hipvoc_debug_stage(void *h, const int64_t *codes, int n_frames, int stage, f
     std::vector<long long> cv(codes, codes + (size_t)n_frames * c->n_q);
     for (long long v : cv)
         if (v < 0 || v >= c->cb_size) { c->err = "code index outside [0, codebook_size)"; return HIPVOC_E_CODE; }
-    Plan *p = get_plan(c, 1, n_frames);
+    Plan *p = get_plan(c, 1, n_frames, true);
     if (!p) return HIPVOC_E_HIP;
     int64_t Lu = c->out_len(n_frames);
     size_t stride = (size_t)rupl(std::max<int64_t>(Lu, 1), 64);

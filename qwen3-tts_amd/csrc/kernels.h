@@ -28,6 +28,10 @@ struct ConvGemmArgs {
     const float *bias2;   // [N] or null
     const float *sn2_a;   // [N]
     const float *sn2_ib;  // [N]
+    // optional SnakeBeta applied to the OUTPUT (after bias/residual): the activation that opens the next
+    // decoder block, evaluated once here instead of once per row tile of the consumer
+    const float *psn_a;   // [N] or null
+    const float *psn_ib;
     int Cin, N, NP, TN;
     int ntaps, shift0, shift_step;   // shift(tap) = shift0 + tap*shift_step
     int S;                           // out channel = n / S, out position = m*S + n % S

@@ -280,12 +280,15 @@ __global__ __launch_bounds__(NTH, (FUSE && TN > 4) ? 2 : 4) void conv_gemm_kerne
             // + b2 + residual x, store this 32-row tile
             const float *b2p = launder_after(a.bias2, acc2[15]);
             const float *rup = launder_after(a.res, acc2[15]) + (long)unit * a.y_us;
+            const float *pa = launder_after(a.psn_a, acc2[15]), *pb = launder_after(a.psn_ib, acc2[15]);
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 int n = o * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (n >= a.N || m >= a.M) continue;
                 long oo = (long)n * a.y_cs + m;
-                yu[oo] = rup[oo] + (acc2[r] + b2p[n]);
+                float v = rup[oo] + (acc2[r] + b2p[n]);
+                if (pa) v = snake_beta(v, pa[n], pb[n]);
+                yu[oo] = v;
             }
         }
 #undef W2_LOAD
@@ -298,6 +301,7 @@ __global__ __launch_bounds__(NTH, (FUSE && TN > 4) ? 2 : 4) void conv_gemm_kerne
     const float *ru0 = launder_after(a.res, acc[TN - 1][15]);
     const float *ru = ru0 ? ru0 + (long)unit * a.y_us : nullptr;
     const float *bp = launder_after(a.bias, acc[TN - 1][15]), *scp = launder_after(a.rscale, acc[TN - 1][15]);
+    const float *pa = launder_after(a.psn_a, acc[TN - 1][15]), *pb = launder_after(a.psn_ib, acc[TN - 1][15]);
     const int m = m0 + wave * 32 + l31;
 #pragma unroll
     for (int i = 0; i < TN; i++) {
@@ -315,6 +319,7 @@ __global__ __launch_bounds__(NTH, (FUSE && TN > 4) ? 2 : 4) void conv_gemm_kerne
             long o = (long)co * a.y_cs + (long)m * a.S + ph;
             if (ru) v = ru[o] + v;
             if (a.act == ACT_CLAMP1) v = fminf(fmaxf(v, -1.0f), 1.0f);
+            if (pa) v = snake_beta(v, pa[co], pb[co]);
             yu[o] = v;
         }
     }
