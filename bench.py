@@ -34,6 +34,23 @@ AUDIO_S_PER_UTT = FRAMES_PER_UTT * 1920 / 24000.0
 PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 
 
+def pmc_traffic(kernel, units_per_pass):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic_*.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate runs, corrected as MI355X_MICROARCH.md prescribes).  PMC
+    counters cannot be read from inside this process, so the figure is the last profiled one, valid only for
+    the same kernel symbol and pass size; otherwise null."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic_*.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        k = d.get("kernels", {}).get(kernel.replace(" ", ""))
+        if k and d.get("units_per_pass") == units_per_pass:
+            return k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"], os.path.relpath(path, ROOT)
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -136,8 +153,10 @@ def main():
         dom = max(kernels, key=lambda n: kernels[n]["ms"])
         kd = kernels[dom]
         achieved = kd["flops"] / (kd["ms"] * 1e-3) / 1e12
+        traffic, traffic_src = pmc_traffic(dom, G)
         roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "traffic_source": traffic_src,
                     "avg_launch_ms": round(kd["ms"] / kd["launches"], 4), "launches_per_pass": kd["launches"],
                     "units_per_pass": G, "share_of_pass_time": round(kd["ms"] / sum(k["ms"] for k in kernels.values()), 3)}
 

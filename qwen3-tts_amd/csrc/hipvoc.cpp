@@ -94,6 +94,8 @@ struct Ctx {
     bool profile = false;
     bool fuse_res = true;
     bool post_snake = true;
+    int dual_out = 1;          // un-fused residual units, SnakeBeta in the producer's epilogue: 0 never, 1 conv7 -> conv1 only
+                               // (no extra write), 2 also x / snake(x) written side by side (HIPVOC_DUAL)
     hipStream_t stream = nullptr;
     std::string err;
     std::vector<void *> dev_allocs;
@@ -464,7 +466,7 @@ static bool load_model(Ctx *c, const char *path, std::string &err) {
 
 // ---------------------------------------------------------------------------------------------
 // workspace + plan
-enum BufId { B_RVQ = 1, B_SUMS, B_PRE, B_H, B_XN, B_QKV, B_AO, B_GU, B_BIG0, B_BIG1, B_BIG2 };
+enum BufId { B_RVQ = 1, B_SUMS, B_PRE, B_H, B_XN, B_QKV, B_AO, B_GU, B_BIG0, B_BIG1, B_BIG2, B_SNK };
 
 struct PlanBuilder {
     Ctx *c;
@@ -502,9 +504,9 @@ struct PlanBuilder {
 
     // x[Cin][G][Lpi] -> y[N/S][G][Lpo]
     void gemm(const char *name, const Gemm &g, const float *x, int Lin, int Lpi, float *y, int Lpo, const Snake *sn,
-              const float *res, const float *rscale, int act, const Snake *post = nullptr) {
+              const float *res, const float *rscale, int act, const Snake *post = nullptr, float *y2 = nullptr) {
         ConvGemmArgs a{};
-        a.x = x; a.y = y; a.w = g.w; a.bias = g.bias; a.res = res; a.rscale = rscale;
+        a.x = x; a.y = y; a.w = g.w; a.bias = g.bias; a.res = res; a.rscale = rscale; a.y2 = post ? y2 : nullptr;
         a.psn_a = post ? post->ea : nullptr; a.psn_ib = post ? post->ib : nullptr;
         a.sn_a = sn ? sn->ea : nullptr; a.sn_ib = sn ? sn->ib : nullptr;
         a.Cin = g.Cin; a.N = g.N; a.NP = g.NP; a.TN = g.TN;
@@ -606,7 +608,11 @@ static Plan *get_plan(Ctx *c, int G, int T, bool debug = false) {
         xn = h;
     }
     // big ping-pong buffers: size = the largest decoder-side tensor
-    size_t big = 0;
+    auto blk_fused = [c](const Ctx::Block &blk) {
+        return c->fuse_res && PlanBuilder::can_fuse(blk.res[0].c1, blk.res[0].c2) &&
+               PlanBuilder::can_fuse(blk.res[1].c1, blk.res[1].c2) && PlanBuilder::can_fuse(blk.res[2].c1, blk.res[2].c2);
+    };
+    size_t big = 0, snk_floats = 0;
     {
         long L = T;
         int C = c->latent;
@@ -621,9 +627,12 @@ static Plan *get_plan(Ctx *c, int G, int T, bool debug = false) {
             L = (L - 1) * c->rates[i];
             C = c->blocks[i].tc.N / c->rates[i];
             big = std::max(big, (size_t)C * rup((int)L, 4));
+            if (c->dual_out >= 2 && !blk_fused(c->blocks[i])) snk_floats = std::max(snk_floats, (size_t)C * rup((int)L, 4) * G);
         }
         big *= G;
     }
+    float *snk_buf = snk_floats ? b.buf(B_SNK, snk_floats) : nullptr;
+    if (snk_floats && !snk_buf) return nullptr;
     float *cur = b.buf(B_BIG0, big), *t1 = b.buf(B_BIG1, big), *t2 = b.buf(B_BIG2, big);
     if (b.fail || !cur || !t1 || !t2) return nullptr;
     b.gemm("proj", c->out_proj, xn, T, Tp, cur, Tp, nullptr, nullptr, nullptr, ACT_NONE);
@@ -671,16 +680,35 @@ static Plan *get_plan(Ctx *c, int G, int T, bool debug = false) {
         int r = c->rates[bi];
         int L2 = (L - 1) * r, Lp2 = rup(L2, 4);
         size_t ni = std::min<size_t>(bi, 4);
-        b.gemm(tc_names[ni], blk.tc, cur, L, Lp, t1, Lp2, post_snake ? nullptr : &blk.s, nullptr, nullptr, ACT_NONE);
+        // Un-fused residual units (blocks whose channels do not fit one row tile): every SnakeBeta of the chain is
+        // evaluated by the PRODUCER of the tensor it acts on, once per element, instead of in the consumer's
+        // staging loop once per row tile: the trans-conv / the previous unit's conv1 write x (raw, the residual)
+        // and snake_s1(x) side by side; conv7 writes snake_s2(H) only.  Same fp32 operations on the same values,
+        // so results are bit-identical to the consumer-side form.
+        const bool fused_blk = blk_fused(blk);
+        const bool dual = c->dual_out >= 2 && !fused_blk;
+        const int Cn = blk.tc.N / r;
+        float *snk = dual ? snk_buf : nullptr;
+        b.gemm(tc_names[ni], blk.tc, cur, L, Lp, t1, Lp2, post_snake ? nullptr : &blk.s, nullptr, nullptr, ACT_NONE,
+               dual ? &blk.res[0].s1 : nullptr, snk);
         std::swap(cur, t1);
-        L = L2; Lp = Lp2; C = blk.tc.N / r;
+        L = L2; Lp = Lp2; C = Cn;
         b.mark(st++, cur, C, L, Lp);
         for (int u = 0; u < 3; u++) {
             const Ctx::Res &ru = blk.res[u];
             const Snake *post = (post_snake && u == 2 && bi + 1 < c->blocks.size()) ? &c->blocks[bi + 1].s : nullptr;
-            if (c->fuse_res && PlanBuilder::can_fuse(ru.c1, ru.c2)) {
+            if (fused_blk) {
                 b.res_unit_fused(ru_names[ni], ru.c1, ru.c2, ru.s1, ru.s2, cur, L, Lp, t1, post);
                 std::swap(cur, t1);
+            } else if (dual) {
+                b.gemm(c7_names[ni], ru.c1, snk, L, Lp, t1, Lp, nullptr, nullptr, nullptr, ACT_NONE, &ru.s2);
+                if (u < 2)
+                    b.gemm(c1_names[ni], ru.c2, t1, L, Lp, cur, Lp, nullptr, cur, nullptr, ACT_NONE, &blk.res[u + 1].s1, snk);
+                else
+                    b.gemm(c1_names[ni], ru.c2, t1, L, Lp, cur, Lp, nullptr, cur, nullptr, ACT_NONE, post);
+            } else if (c->dual_out == 1) {
+                b.gemm(c7_names[ni], ru.c1, cur, L, Lp, t1, Lp, &ru.s1, nullptr, nullptr, ACT_NONE, &ru.s2);
+                b.gemm(c1_names[ni], ru.c2, t1, L, Lp, cur, Lp, nullptr, cur, nullptr, ACT_NONE, post);
             } else {
                 b.gemm(c7_names[ni], ru.c1, cur, L, Lp, t1, Lp, &ru.s1, nullptr, nullptr, ACT_NONE);
                 b.gemm(c1_names[ni], ru.c2, t1, L, Lp, cur, Lp, &ru.s2, cur, nullptr, ACT_NONE, post);
@@ -878,6 +906,7 @@ void *hipvoc_load(const char *weights_path, int device_id, int dtype, int unit_f
     if (const char *pf = getenv("HIPVOC_PROFILE")) c->profile = atoi(pf) != 0;
     if (const char *fz = getenv("HIPVOC_FUSE")) c->fuse_res = atoi(fz) != 0;
     if (const char *ps = getenv("HIPVOC_POST_SNAKE")) c->post_snake = atoi(ps) != 0;
+    if (const char *ps = getenv("HIPVOC_DUAL")) c->dual_out = atoi(ps);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
     std::string err;
     if (!load_model(c.get(), weights_path, err)) return fail(err);

@@ -32,6 +32,7 @@ struct ConvGemmArgs {
     // decoder block, evaluated once here instead of once per row tile of the consumer
     const float *psn_a;   // [N] or null
     const float *psn_ib;
+    float *y2;            // with psn_*: y keeps the raw value and y2 (layout of y) gets the activated one
     int Cin, N, NP, TN;
     int ntaps, shift0, shift_step;   // shift(tap) = shift0 + tap*shift_step
     int S;                           // out channel = n / S, out position = m*S + n % S

@@ -225,6 +225,16 @@ __global__ __launch_bounds__(NTH, (FUSE && TN > 4) ? 2 : 4) void conv_gemm_kerne
     if constexpr (FUSE) {
         // H = snake2(acc + b1), in place.  Register r of tile i is channel i*32 + (r&3) + 8*(r>>2) + 4*h.
         // bias / snake vectors are zero-padded by the loader, so padded rows stay exactly 0.
+        const float *w2p = launder_after(a.w2, acc[0][15]);
+        {
+            constexpr int W2F4 = 256 * TN;
+            // tile 0 of the second product's weights: in flight during the activation below
+            if (tid < W2F4) xr0 = *reinterpret_cast<const float4 *>(w2p + (long)(tid >> 3) * a.NP + (tid & 7) * 4);
+            if (W2F4 > NTH && tid + NTH < W2F4)
+                xr1 = *reinterpret_cast<const float4 *>(w2p + (long)((tid + NTH) >> 3) * a.NP + (tid & 7) * 4);
+            if (W2F4 > 2 * NTH && tid + 2 * NTH < W2F4)
+                xr2 = *reinterpret_cast<const float4 *>(w2p + (long)((tid + 2 * NTH) >> 3) * a.NP + (tid & 7) * 4);
+        }
 #pragma unroll
         for (int i = 0; i < TN; i++) {
             const float *b1p = launder_after(a.bias, acc[i][15]), *s2a = launder_after(a.sn2_a, acc[i][15]),
@@ -235,48 +245,61 @@ __global__ __launch_bounds__(NTH, (FUSE && TN > 4) ? 2 : 4) void conv_gemm_kerne
                 acc[i][r] = snake_beta(acc[i][r] + b1p[n], s2a[n], s2b[n]);
                 // four activations in flight at a time: unbounded, the scheduler interleaves all 16*TN
                 // polynomial chains and their temporaries spill
-                if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                if ((r & 3) == 3) {
+                    // ... and the results are pinned here: without it LLVM sinks the polynomial tails to their first
+                    // use in the second product, where all 16*TN chains become live at once
+                    asm volatile("" : "+v"(acc[i][r - 3]), "+v"(acc[i][r - 2]), "+v"(acc[i][r - 1]), "+v"(acc[i][r]));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
         // second product, ONE 32-row output tile at a time (16 accumulator registers instead of 16*TN, so
-        // the C=96 unit still runs four waves per SIMD); its weights go through the same Ws double
-        // buffer, as [16 k rows][32 output rows] stages (8 registers of H each)
+        // the C=96 unit still runs four waves per SIMD).  Its weights W2[:, 32o..32o+32) are staged as WHOLE
+        // [32*TN k rows][32 output rows] tiles, double-buffered over the (now free) Xs/Ws area through the
+        // activation prefetch registers: one barrier per output tile, 16*TN MFMAs between barriers.
         float *yu = a.y + (long)unit * a.y_us;
         const int m = m0 + wave * 32 + l31;
-        // W2 stage (s2, o): rows [16*s2, 16*s2+16) x columns [32*o, 32*o+32) of the packed [NP][NP] tensor:
-        // 128 float4, loaded by the first 128 threads
-        const int w2k = tid >> 3, w2c = (tid & 7) * 4;
-        float4 w2r = make_float4(0.f, 0.f, 0.f, 0.f);
-#define W2_LOAD(s2_, o_) { if (tid < 128) w2r = *reinterpret_cast<const float4 *>(a.w2 + (long)((s2_) * BK + w2k) * a.NP + (o_) * 32 + w2c); }
-#define W2_STORE(buf_) { if (tid < 128) *reinterpret_cast<float4 *>(Ws + (buf_) * (BK * 32) + w2k * 32 + w2c) = w2r; }
-        W2_LOAD(0, 0)
-        __syncthreads();                          // every wave is done with the main loop's Ws
-        W2_STORE(0)
-        int buf = 0;
+        constexpr int W2F4 = 256 * TN;            // float4 per tile
+        constexpr int W2T = 32 * TN * 32;         // floats per tile
+#define W2_FETCH(o_)                                                                                                  \
+    {                                                                                                                 \
+        const float *wq_ = launder_after(a.w2, dep2) + (o_) * 32;                                                     \
+        if (tid < W2F4) xr0 = *reinterpret_cast<const float4 *>(wq_ + (long)(tid >> 3) * a.NP + (tid & 7) * 4);       \
+        if (W2F4 > NTH && tid + NTH < W2F4)                                                                           \
+            xr1 = *reinterpret_cast<const float4 *>(wq_ + (long)((tid + NTH) >> 3) * a.NP + (tid & 7) * 4);           \
+        if (W2F4 > 2 * NTH && tid + 2 * NTH < W2F4)                                                                   \
+            xr2 = *reinterpret_cast<const float4 *>(wq_ + (long)((tid + 2 * NTH) >> 3) * a.NP + (tid & 7) * 4);       \
+    }
+#define W2_COMMIT(buf_)                                                                                               \
+    {                                                                                                                 \
+        float *wd_ = smem + (buf_) * W2T + tid * 4;                                                                   \
+        if (tid < W2F4) *reinterpret_cast<float4 *>(wd_) = xr0;                                                       \
+        if (W2F4 > NTH && tid + NTH < W2F4) *reinterpret_cast<float4 *>(wd_ + 4 * NTH) = xr1;                         \
+        if (W2F4 > 2 * NTH && tid + 2 * NTH < W2F4) *reinterpret_cast<float4 *>(wd_ + 8 * NTH) = xr2;                 \
+    }
+        __syncthreads();                          // every wave is done with the main loop's Xs / Ws
+        W2_COMMIT(0)
+        float dep2 = acc[TN - 1][15];             // pins each tile's weight fetch behind the previous tile's product
 #pragma unroll
         for (int o = 0; o < TN; o++) {
+            if (o + 1 < TN) W2_FETCH(o + 1)
+            __syncthreads();                      // tile o visible; tile o-1's readers are past
             f32x16 acc2;
 #pragma unroll
             for (int r = 0; r < 16; r++) acc2[r] = 0.0f;
+            const float *ws = smem + (o & 1) * W2T + l31 + 4 * h * 32;
 #pragma unroll
-            for (int s2 = 0; s2 < 2 * TN; s2++) {
-                const int i = s2 >> 1, half = s2 & 1;
-                const bool last = (o == TN - 1) && (s2 == 2 * TN - 1);
-                if (!last) {
-                    const int s2n = s2 + 1 < 2 * TN ? s2 + 1 : 0, on = s2 + 1 < 2 * TN ? o : o + 1;
-                    W2_LOAD(s2n, on)
-                }
-                __syncthreads();
-                const float *ws = Ws + buf * (BK * 32) + l31;
+            for (int i = 0; i < TN; i++)
 #pragma unroll
-                for (int rr = 0; rr < 8; rr++) {
-                    const int r = half * 8 + rr;
-                    int k = (rr & 3) + 8 * (rr >> 2) + 4 * h;   // row inside this 16-row stage of the k this lane half holds in register r
+                for (int r = 0; r < 16; r++) {
+                    // register r of tile i holds channel i*32 + (r&3) + 8*(r>>2) + 4h: that is this lane half's k
+                    const int k = i * 32 + (r & 3) + 8 * (r >> 2);
                     acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ws[k * 32], acc[i][r], acc2, 0, 0, 0);
+                    // keep the LDS reads of at most 8 steps in flight (unbounded, all 16*TN are hoisted and spill)
+                    if ((r & 7) == 7) __builtin_amdgcn_sched_barrier(0);
                 }
-                buf ^= 1;
-                if (!last) W2_STORE(buf)
-            }
+            if (o + 1 < TN) W2_COMMIT((o + 1) & 1)
+            dep2 = acc2[15];
             // + b2 + residual x, store this 32-row tile
             const float *b2p = launder_after(a.bias2, acc2[15]);
             const float *rup = launder_after(a.res, acc2[15]) + (long)unit * a.y_us;
@@ -291,8 +314,8 @@ __global__ __launch_bounds__(NTH, (FUSE && TN > 4) ? 2 : 4) void conv_gemm_kerne
                 yu[oo] = v;
             }
         }
-#undef W2_LOAD
-#undef W2_STORE
+#undef W2_FETCH
+#undef W2_COMMIT
         return;
     }
 
@@ -302,6 +325,8 @@ __global__ __launch_bounds__(NTH, (FUSE && TN > 4) ? 2 : 4) void conv_gemm_kerne
     const float *ru = ru0 ? ru0 + (long)unit * a.y_us : nullptr;
     const float *bp = launder_after(a.bias, acc[TN - 1][15]), *scp = launder_after(a.rscale, acc[TN - 1][15]);
     const float *pa = launder_after(a.psn_a, acc[TN - 1][15]), *pb = launder_after(a.psn_ib, acc[TN - 1][15]);
+    float *y2u0 = launder_after(a.y2, acc[TN - 1][15]);
+    float *y2u = y2u0 ? y2u0 + (long)unit * a.y_us : nullptr;
     const int m = m0 + wave * 32 + l31;
 #pragma unroll
     for (int i = 0; i < TN; i++) {
@@ -319,8 +344,12 @@ __global__ __launch_bounds__(NTH, (FUSE && TN > 4) ? 2 : 4) void conv_gemm_kerne
             long o = (long)co * a.y_cs + (long)m * a.S + ph;
             if (ru) v = ru[o] + v;
             if (a.act == ACT_CLAMP1) v = fminf(fmaxf(v, -1.0f), 1.0f);
-            if (pa) v = snake_beta(v, pa[co], pb[co]);
-            yu[o] = v;
+            if (pa) {
+                float sv = snake_beta(v, pa[co], pb[co]);
+                if (y2u) { yu[o] = v; y2u[o] = sv; } else yu[o] = sv;
+            } else {
+                yu[o] = v;
+            }
         }
     }
 }
@@ -364,7 +393,10 @@ const char *conv_gemm_kernel_name(const ConvGemmArgs &a) {
 size_t conv_gemm_lds_bytes(const ConvGemmArgs &a) {
     int HL, XW;
     conv_gemm_geometry(a, HL, XW);
-    return sizeof(float) * (2 * (size_t)BK * XW + 2 * (size_t)BK * 32 * conv_gemm_launch_tn(a));
+    const int tn = conv_gemm_launch_tn(a);
+    size_t fl = 2 * (size_t)BK * XW + 2 * (size_t)BK * 32 * tn;
+    if (a.w2) fl = fl > 2 * (size_t)32 * tn * 32 ? fl : 2 * (size_t)32 * tn * 32;   // two W2 tiles of the fused second product
+    return sizeof(float) * fl;
 }
 
 template <int TN, bool FUSE>
@@ -401,6 +433,7 @@ hipError_t launch_conv_gemm(const ConvGemmArgs &a_in, hipStream_t s) {
         ((uintptr_t)a.x & 15) || ((uintptr_t)a.w & 15) || a.ntaps < 1 || a.S < 1 || BK * (XW / 4) > 3 * NTH)
         return hipErrorInvalidValue;
     const int tn = conv_gemm_launch_tn(a);
+    if (a.y2 && (!a.psn_a || !a.psn_ib || a.w2)) return hipErrorInvalidValue;
     if (a.w2 && (a.S != 1 || a.NP != 32 * tn || (a.N + 31) / 32 != tn || tn == 5 || tn > 6 || !a.res || !a.sn2_a ||
                  !a.sn2_ib || !a.bias || !a.bias2 || ((uintptr_t)a.w2 & 15)))
         return hipErrorInvalidValue;
