@@ -32,6 +32,7 @@ UTTERANCES_PER_GPU = 256
 FRAMES_PER_UTT = 125            # 10.0 s at 12.5 Hz
 AUDIO_S_PER_UTT = FRAMES_PER_UTT * 1920 / 24000.0
 PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md, dense bf16
 
 
 def pmc_traffic(kernel, units_per_pass):
@@ -58,6 +59,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--utterances", type=int, default=UTTERANCES_PER_GPU)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="f32 (default; the reference's precision and the headline number) or the bf16 conv-GEMM mode "
+                         "(BASELINE configs[4]; separately stated tolerance, never the default)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -79,7 +83,7 @@ def main():
     W = synth.make_weights(cfg, 0)
     wpath = os.path.join(tempfile.gettempdir(), f"hipvoc_bench_full_r{rank}.safetensors")
     synth.save_safetensors(wpath, W, cfg.metadata())
-    voc = pkg.HipVocoder.load(wpath, device=local_rank, unit_frames=64)
+    voc = pkg.HipVocoder.load(wpath, device=local_rank, unit_frames=64, dtype=1 if args.dtype == "bf16" else 0)
     os.remove(wpath)
 
     # --- synthetic workload: utterance u of rank r uses seed 1000 + r*U + u
@@ -154,8 +158,9 @@ def main():
         kd = kernels[dom]
         achieved = kd["flops"] / (kd["ms"] * 1e-3) / 1e12
         traffic, traffic_src = pmc_traffic(dom, G)
-        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+        peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
+        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 3), "peak": peak,
+                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                     "traffic_source": traffic_src,
                     "avg_launch_ms": round(kd["ms"] / kd["launches"], 4), "launches_per_pass": kd["launches"],
                     "units_per_pass": G, "share_of_pass_time": round(kd["ms"] / sum(k["ms"] for k in kernels.values()), 3)}
@@ -188,9 +193,10 @@ def main():
             "metric": "vocoder audio-sec/sec (xRT)", "value": round(value, 2), "unit": "audio-sec/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"configs[2]: batched decode of {U} synthetic 10 s code sequences per GPU "
-                                   f"(125 frames x 16 codebooks -> 2 reference units of 64 frames each), fp32, "
+                                   f"(125 frames x 16 codebooks -> 2 reference units of 64 frames each), "
+                                   f"{'fp32' if args.dtype == 'f32' else 'bf16 conv-GEMM mode (fp32 accumulate; parity_vs_oracle is against the fp32 oracle)'}, "
                                    f"seeded random-init weights of the Qwen3-TTS 12 Hz decoder (114 M params)",
                        "utterances_per_gpu": U, "units_per_gpu": n_units, "unit_frames": T,
                        "units_per_pass": voc.group_units},

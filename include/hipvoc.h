@@ -32,7 +32,9 @@ extern "C" {
 #define HIPVOC_E_MODEL (-6)     /* weights file unreadable / unsupported architecture */
 
 #define HIPVOC_DTYPE_F32 0
-#define HIPVOC_DTYPE_BF16 1     /* bf16 conv-GEMM mode (reserved; hipvoc_load rejects it for now) */
+#define HIPVOC_DTYPE_BF16 1     /* bf16 conv-GEMM mode: operands of every conv / linear / transposed conv rounded to bf16
+                                   (RNE), fp32 accumulate; RVQ, norms, attention, SnakeBeta, residuals and the final
+                                   C->1 conv stay fp32.  Tolerance: see DESIGN.md / tests (not the fp32 gates). */
 
 #define HIPVOC_SAMPLES_PER_TOKEN 1920   /* src/worker/vocoder.rs:6, src/protocol.rs:122 */
 

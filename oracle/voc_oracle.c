@@ -58,6 +58,10 @@ typedef struct VocOracle {
     int sliding_window;
     float rope_theta;
     float rms_eps;
+    /* 1: emulate the bf16 conv-GEMM mode of the HIP library: the input and the weights of every conv / linear /
+     * transposed conv with more than one output channel are rounded to bf16 (nearest even), products and sums
+     * stay fp32.  0 (default): the reference's fp32 arithmetic. */
+    int bf16_gemm;
     /* derived */
     int finalized;
     int n_q, cb_size, cb_dim, q_out, latent, hidden, n_layers, qkv_dim, head_dim, inter;
@@ -90,6 +94,7 @@ int voc_oracle_set_param(VocOracle *o, const char *name, double v) {
     else if (!strcmp(name, "sliding_window")) o->sliding_window = (int)v;
     else if (!strcmp(name, "rope_theta")) o->rope_theta = (float)v;
     else if (!strcmp(name, "rms_norm_eps")) o->rms_eps = (float)v;
+    else if (!strcmp(name, "bf16_gemm")) o->bf16_gemm = v != 0;
     else return -1;
     return 0;
 }
@@ -211,10 +216,39 @@ int64_t voc_oracle_out_len(const VocOracle *o, int T) {
 /* ------------------------------------------------------------------------------------------ */
 /* Primitive ops, channel-first [C][L].                                                        */
 
+static int g_bf16 = 0; /* set from o->bf16_gemm on entry of decoder_forward (the oracle is not re-entrant) */
+
+static inline float bf16_round(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    u &= 0xffff0000u;
+    memcpy(&f, &u, 4);
+    return f;
+}
+static float *bf16_copy(const float *x, int64_t n) {
+    float *r = (float *)malloc(sizeof(float) * (size_t)n);
+#pragma omp parallel for
+    for (int64_t i = 0; i < n; i++) r[i] = bf16_round(x[i]);
+    return r;
+}
+
 /* Causal Conv1d, stride 1, groups=1 (TF:3180-3213): left pad (K-1)*dil zeros, no right pad.
  * w[Cout][Cin][K].  y[co][t] = b[co] + sum_ci sum_j w[co][ci][j] * x[ci][t-(K-1-j)*dil]. */
+static void conv1d_causal_f32(const float *x, int Cin, int64_t L, const float *w, const float *b, int Cout, int K,
+                              int dil, float *y);
 static void conv1d_causal(const float *x, int Cin, int64_t L, const float *w, const float *b, int Cout, int K,
                           int dil, float *y) {
+    if (g_bf16 && Cout > 1) {
+        float *xr = bf16_copy(x, (int64_t)Cin * L), *wr = bf16_copy(w, (int64_t)Cout * Cin * K);
+        conv1d_causal_f32(xr, Cin, L, wr, b, Cout, K, dil, y);
+        free(xr); free(wr);
+        return;
+    }
+    conv1d_causal_f32(x, Cin, L, w, b, Cout, K, dil, y);
+}
+static void conv1d_causal_f32(const float *x, int Cin, int64_t L, const float *w, const float *b, int Cout, int K,
+                              int dil, float *y) {
     enum { TB = 512, CB = 4 };
     int64_t ntb = (L + TB - 1) / TB;
     int ncb = (Cout + CB - 1) / CB;
@@ -280,8 +314,10 @@ static void dwconv_causal(const float *x, int C, int64_t L, const float *w, cons
  * full[co][i*s+j] = b[co] + sum_ci x[ci][i]*w[ci][co][j];  y = full[:, pad : Lfull-pad]. */
 static int64_t transconv_len(int64_t L, int K, int s) { return (L - 1) * s + K - 2 * (K - s); }
 
-static void transconv_causal(const float *x, int Cin, int64_t L, const float *w, const float *b, int Cout, int K,
+static void transconv_causal(const float *x_in, int Cin, int64_t L, const float *w_in, const float *b, int Cout, int K,
                              int s, float *y) {
+    float *xr = g_bf16 ? bf16_copy(x_in, (int64_t)Cin * L) : NULL, *wr = g_bf16 ? bf16_copy(w_in, (int64_t)Cin * Cout * K) : NULL;
+    const float *x = xr ? xr : x_in, *w = wr ? wr : w_in;
     int pad = K - s;
     int64_t Lf = (L - 1) * s + K, Lo = Lf - 2 * pad;
 #pragma omp parallel
@@ -306,6 +342,7 @@ static void transconv_causal(const float *x, int Cin, int64_t L, const float *w,
         free(full);
         free(tmp);
     }
+    free(xr); free(wr);
 }
 
 /* SnakeBeta (TF:3566-3580): x + (1/(exp(beta)+1e-9)) * sin(x*exp(alpha))^2, per channel. */
@@ -502,6 +539,7 @@ static int decoder_forward(VocOracle *o, const int64_t *codes, int T, float *wav
     if (!o->finalized) { snprintf(o->err, sizeof o->err, "not finalized"); return -1; }
     if (T < 1 || T > 4096) { snprintf(o->err, sizeof o->err, "bad T"); return -1; }
     o->err[0] = 0;
+    g_bf16 = o->bf16_gemm;
     int st = 0;
     /* g1: RVQ */
     float *sums = (float *)malloc(sizeof(float) * 2 * o->cb_dim * T);

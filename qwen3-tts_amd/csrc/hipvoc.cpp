@@ -45,7 +45,9 @@ static inline long rupl(long v, long m) { return (v + m - 1) / m * m; }
 
 // One conv / linear / transposed conv, packed for conv_gemm.
 struct Gemm {
-    float *w = nullptr;      // device [ntaps][CinP][NP]
+    float *w = nullptr;      // device [ntaps][CinP][NP] (fp32 mode)
+    unsigned short *wb = nullptr;    // bf16 mode: [ntaps][CinP/32][4][NP][8] bf16 (kernels_bf16.hip)
+    unsigned short *wb2 = nullptr;   // bf16 mode, 1x1 conv of a fusable residual unit: accumulator-order packing
     float *bias = nullptr;   // device [N/S] or null
     int Cin = 0, N = 0, NP = 0, TN = 0, ntaps = 1, shift0 = 0, step = 0, S = 1;
 };
@@ -94,6 +96,7 @@ struct Ctx {
     bool profile = false;
     bool fuse_res = true;
     bool post_snake = true;
+    bool bf16 = false;         // HIPVOC_DTYPE_BF16: conv-GEMM operands in bf16, fp32 accumulate, everything else fp32
     int dual_out = 1;          // un-fused residual units, SnakeBeta in the producer's epilogue: 0 never, 1 conv7 -> conv1 only
                                // (no extra write), 2 also x / snake(x) written side by side (HIPVOC_DUAL)
     hipStream_t stream = nullptr;
@@ -202,6 +205,61 @@ struct Loader {
         c->dev_allocs.push_back(p);
         return (float *)p;
     }
+    static unsigned short to_bf16(float f) {   // round to nearest even (what v_cvt_pk_bf16_f32 does)
+        uint32_t u;
+        memcpy(&u, &f, 4);
+        if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);   // NaN stays NaN
+        u += 0x7fffu + ((u >> 16) & 1u);
+        return (unsigned short)(u >> 16);
+    }
+    unsigned short *upload_u16(const std::vector<unsigned short> &v) {
+        if (!ok) return nullptr;
+        void *p = nullptr;
+        size_t bytes = (v.size() + 512) * sizeof(unsigned short);
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e == hipSuccess) e = hipMemset(p, 0, bytes);
+        if (e == hipSuccess) e = hipMemcpy(p, v.data(), v.size() * sizeof(unsigned short), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            err = std::string("device upload failed: ") + hipGetErrorString(e);
+            ok = false;
+            if (p) (void)hipFree(p);
+            return nullptr;
+        }
+        c->dev_allocs.push_back(p);
+        return (unsigned short *)p;
+    }
+    // fp32 packed [ntaps][CinP][NP] (CinP a multiple of 32) -> the mode's device tensor(s)
+    void finish(Gemm &g, const std::vector<float> &p, int CinP) {
+        if (!c->bf16) { g.w = upload(p); return; }
+        const int ncb = CinP / 32;
+        std::vector<unsigned short> q((size_t)g.ntaps * CinP * g.NP);
+        for (int tap = 0; tap < g.ntaps; tap++)
+            for (int ci = 0; ci < CinP; ci++) {
+                const int cb = ci / 32, kq = (ci % 32) / 8, j = ci % 8;
+                const float *src = &p[((size_t)tap * CinP + ci) * g.NP];
+                unsigned short *dst = &q[((((size_t)tap * ncb + cb) * 4 + kq) * g.NP) * 8 + j];
+                for (int n = 0; n < g.NP; n++) dst[(size_t)n * 8] = to_bf16(src[n]);
+            }
+        g.wb = upload_u16(q);
+        // a square single-tap conv whose rows fit one tile may be the second product of a fused residual unit:
+        // W2 tile o = [2*NP/32 k-steps][2 lane halves][32 rows][8], element (ks = 2i+g, h, row, j) =
+        // w[out = 32o+row][in = 32i + 16g + (j&3) + 8(j>>2) + 4h]  -- the channel a lane half holds in
+        // accumulator register 8g+j of tile i (see kernels_bf16.hip)
+        if (g.ntaps == 1 && g.S == 1 && g.Cin == g.N && CinP == g.NP && g.NP / 32 <= 6) {
+            const int tn = g.NP / 32;
+            std::vector<unsigned short> w2((size_t)tn * 2 * tn * 2 * 32 * 8);
+            for (int o = 0; o < tn; o++)
+                for (int ks = 0; ks < 2 * tn; ks++)
+                    for (int h = 0; h < 2; h++)
+                        for (int row = 0; row < 32; row++)
+                            for (int j = 0; j < 8; j++) {
+                                int in = 32 * (ks >> 1) + 16 * (ks & 1) + (j & 3) + 8 * (j >> 2) + 4 * h;
+                                int out = 32 * o + row;
+                                w2[((((size_t)o * 2 * tn + ks) * 2 + h) * 32 + row) * 8 + j] = to_bf16(p[(size_t)in * g.NP + out]);
+                            }
+            g.wb2 = upload_u16(w2);
+        }
+    }
     float *vec(const std::string &name, int expect) {
         std::vector<float> v;
         std::vector<int64_t> s;
@@ -263,7 +321,7 @@ struct Loader {
                         p[((size_t)j * CinP + ci) * g.NP + n0 + co] = ws[i][((size_t)co * Cin + ci) * K + j];
             n0 += Co;
         }
-        g.w = upload(p);
+        finish(g, p, CinP);
         if (!bias_name.empty()) g.bias = vec(bias_name, N);
         return g;
     }
@@ -295,7 +353,7 @@ struct Loader {
                         p[((size_t)1 * CinP + ci) * g.NP + co * s + r] = w[((size_t)ci * Co + co) * K + r];
                     }
                 }
-        g.w = upload(p);
+        finish(g, p, CinP);
         if (!bias_name.empty()) g.bias = vec(bias_name, Co);
         return g;
     }
@@ -432,7 +490,12 @@ static bool load_model(Ctx *c, const char *path, std::string &err) {
         C = Co;
     }
     c->fin_snake = L.snake(D + fmt("decoder.%d.", nb + 1), C);
-    c->fin = L.conv({D + fmt("decoder.%d.conv.weight", nb + 2)}, D + fmt("decoder.%d.conv.bias", nb + 2), 1);
+    {   // the final C -> 1 conv is HBM-bound and stays fp32 in every mode
+        const bool keep = c->bf16;
+        c->bf16 = false;
+        c->fin = L.conv({D + fmt("decoder.%d.conv.weight", nb + 2)}, D + fmt("decoder.%d.conv.bias", nb + 2), 1);
+        c->bf16 = keep;
+    }
     if (!L.ok) { err = L.err; return false; }
     if (c->fin.N != 1) { err = "final conv must have one output channel"; return false; }
     {
@@ -506,7 +569,7 @@ struct PlanBuilder {
     void gemm(const char *name, const Gemm &g, const float *x, int Lin, int Lpi, float *y, int Lpo, const Snake *sn,
               const float *res, const float *rscale, int act, const Snake *post = nullptr, float *y2 = nullptr) {
         ConvGemmArgs a{};
-        a.x = x; a.y = y; a.w = g.w; a.bias = g.bias; a.res = res; a.rscale = rscale; a.y2 = post ? y2 : nullptr;
+        a.x = x; a.y = y; a.w = g.w; a.wb = g.wb; a.bias = g.bias; a.res = res; a.rscale = rscale; a.y2 = post ? y2 : nullptr;
         a.psn_a = post ? post->ea : nullptr; a.psn_ib = post ? post->ib : nullptr;
         a.sn_a = sn ? sn->ea : nullptr; a.sn_ib = sn ? sn->ib : nullptr;
         a.Cin = g.Cin; a.N = g.N; a.NP = g.NP; a.TN = g.TN;
@@ -527,14 +590,15 @@ struct PlanBuilder {
     // other workgroups still read x's halo, so y must be a different buffer)
     static bool can_fuse(const Gemm &c1, const Gemm &c2) {
         return c1.S == 1 && c2.S == 1 && c2.ntaps == 1 && c2.Cin == c1.N && c2.N == c1.N && c1.NP == c2.NP &&
-               c1.NP / 32 <= 6 && c1.NP / 32 != 5 && (c1.N + 31) / 32 == c1.NP / 32 && c1.bias && c2.bias;
+               c1.NP / 32 <= 6 && c1.NP / 32 != 5 && (c1.N + 31) / 32 == c1.NP / 32 && c1.bias && c2.bias &&
+               (c1.wb == nullptr || c2.wb2 != nullptr);
     }
     void res_unit_fused(const char *name, const Gemm &c1, const Gemm &c2, const Snake &s1, const Snake &s2, const float *x,
                         int L, int Lp, float *y, const Snake *post) {
         ConvGemmArgs a{};
         a.psn_a = post ? post->ea : nullptr; a.psn_ib = post ? post->ib : nullptr;
-        a.x = x; a.y = y; a.w = c1.w; a.bias = c1.bias; a.res = x; a.sn_a = s1.ea; a.sn_ib = s1.ib;
-        a.w2 = c2.w; a.bias2 = c2.bias; a.sn2_a = s2.ea; a.sn2_ib = s2.ib;
+        a.x = x; a.y = y; a.w = c1.w; a.wb = c1.wb; a.bias = c1.bias; a.res = x; a.sn_a = s1.ea; a.sn_ib = s1.ib;
+        a.w2 = c2.w; a.wb2 = c2.wb2; a.bias2 = c2.bias; a.sn2_a = s2.ea; a.sn2_ib = s2.ib;
         a.Cin = c1.Cin; a.N = c1.N; a.NP = c1.NP; a.TN = c1.TN;
         a.ntaps = c1.ntaps; a.shift0 = c1.shift0; a.shift_step = c1.step; a.S = 1; a.act = ACT_NONE;
         a.units = G; a.M = L; a.Lin = L; a.x_us = Lp; a.y_us = Lp; a.x_cs = (long)G * Lp; a.y_cs = (long)G * Lp;
@@ -893,7 +957,7 @@ void *hipvoc_load(const char *weights_path, int device_id, int dtype, int unit_f
         return nullptr;
     };
     if (!weights_path) return fail("weights_path is NULL");
-    if (dtype != HIPVOC_DTYPE_F32) return fail("only HIPVOC_DTYPE_F32 is implemented in this build");
+    if (dtype != HIPVOC_DTYPE_F32 && dtype != HIPVOC_DTYPE_BF16) return fail("dtype must be HIPVOC_DTYPE_F32 or HIPVOC_DTYPE_BF16");
     if (unit_frames < 1 || unit_frames > 4096) return fail("unit_frames out of range");
     int ndev = hipvoc_device_count();
     if (ndev <= 0) return fail("no HIP device available (libhipvoc has no CPU fallback)");
@@ -902,6 +966,7 @@ void *hipvoc_load(const char *weights_path, int device_id, int dtype, int unit_f
     std::unique_ptr<Ctx> c(new Ctx);
     c->device = device_id;
     c->unit_frames = unit_frames;
+    c->bf16 = dtype == HIPVOC_DTYPE_BF16;
     if (const char *g = getenv("HIPVOC_GROUP")) c->group = std::max(1, std::min(256, atoi(g)));
     if (const char *pf = getenv("HIPVOC_PROFILE")) c->profile = atoi(pf) != 0;
     if (const char *fz = getenv("HIPVOC_FUSE")) c->fuse_res = atoi(fz) != 0;

@@ -33,6 +33,11 @@ struct ConvGemmArgs {
     const float *psn_a;   // [N] or null
     const float *psn_ib;
     float *y2;            // with psn_*: y keeps the raw value and y2 (layout of y) gets the activated one
+    // bf16 conv-GEMM mode (kernels_bf16.hip): when wb != null the operands are bf16 (fp32 accumulate) and
+    // w / w2 are unused.  wb: [ntaps][ceil(Cin/32)][4][NP][8] bf16; wb2: fused 1x1 conv, [NP/32 output tiles]
+    // [2*NP/32 k-steps][2][32][8] bf16 in the k order of the accumulator registers (hipvoc.cpp)
+    const unsigned short *wb;
+    const unsigned short *wb2;
     int Cin, N, NP, TN;
     int ntaps, shift0, shift_step;   // shift(tap) = shift0 + tap*shift_step
     int S;                           // out channel = n / S, out position = m*S + n % S
@@ -44,6 +49,13 @@ struct ConvGemmArgs {
     int dbg;                         // timing-only ablation bits (set by the launcher from HIPVOC_DBG; 0 in production)
 };
 hipError_t launch_conv_gemm(const ConvGemmArgs &a, hipStream_t s);
+hipError_t launch_conv_gemm_bf16(const ConvGemmArgs &a, hipStream_t s);
+const char *conv_gemm_bf16_kernel_name(const ConvGemmArgs &a);
+size_t conv_gemm_bf16_lds_bytes(const ConvGemmArgs &a);
+namespace detail {
+void conv_gemm_geometry(const ConvGemmArgs &a, int &HL, int &XW);   // halo (left, multiple of 4) and LDS tile width
+int conv_gemm_launch_tn(const ConvGemmArgs &a);                     // row-tile height actually launched
+}
 // kernel symbol family actually launched for these args (profiling labels)
 const char *conv_gemm_kernel_name(const ConvGemmArgs &a);
 size_t conv_gemm_lds_bytes(const ConvGemmArgs &a);

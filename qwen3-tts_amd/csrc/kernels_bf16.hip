@@ -1,0 +1,353 @@
+// gfx950 (CDNA4 / MI355X) bf16 conv-GEMM mode of the vocoder path (HIPVOC_DTYPE_BF16, BASELINE configs[4]).
+//
+// Same orientation and tiling as the fp32 kernel (kernels.hip): weights are the A operand, activations the
+// B operand (time on the lane), 8 waves x 32 positions per workgroup, accumulators in fp32.  What changes:
+//   * v_mfma_f32_32x32x16_bf16: each lane supplies EIGHT consecutive k of its row / column, so both LDS
+//     tiles are laid out as [k/8][row or position][8 bf16]: one ds_read_b128 per operand, and a conv tap is
+//     still a shift along the position axis of the same activation tile;
+//   * the activation tile is built from the channel-first fp32 tensors in HBM: a thread gathers the eight
+//     channels of one (k-group, position), applies SnakeBeta in fp32, rounds to bf16 (RNE) and writes one
+//     16-byte LDS element; everything in HBM stays fp32 (residual stream, biases, epilogues);
+//   * weights are rounded to bf16 once at load and stored in exactly the LDS tile order;
+//   * fused residual unit: the fp32 accumulator becomes the second product's B operand by a pure
+//     register-local pack (a lane's registers 8g..8g+7 are its eight k of MFMA g); the k order this implies
+//     is baked into the packing of the 1x1 conv's weights on the host (hipvoc.cpp: pack_w2_bf16).
+#include "device_common.h"
+#include "kernels.h"
+
+#include <cstdio>
+
+namespace hipvoc {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+static constexpr int BMB = 256;   // positions per workgroup
+static constexpr int BKB = 32;    // input channels per K block (two MFMA k-steps)
+static constexpr int NTHB = 512;  // 8 waves
+
+__device__ __forceinline__ bf16x8 pack8(const f32x8 &v) {
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; j++) o[j] = (__bf16)v[j];
+    return o;
+}
+
+template <int TN, bool FUSE>
+__global__ __launch_bounds__(NTHB, (TN > 4) ? 2 : 4) void conv_gemm_bf16_kernel(ConvGemmArgs a, int HL, int XW,
+                                                                                 int tiles_per_unit, int n_tiles) {
+    constexpr int BN = TN * 32;
+    constexpr int WF = 4 * BN;                        // 16-byte elements per W tile [4 k-groups][BN rows]
+    constexpr int WPT = (WF + NTHB - 1) / NTHB;       // per thread: 1 (TN <= 4) or 2 (TN = 6)
+    static_assert(WPT <= 2, "W staging registers");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16x8 *Xs = reinterpret_cast<bf16x8 *>(smem_raw);          // [2][4][XW]
+    bf16x8 *Ws = Xs + 2 * 4 * XW;                                // [2][4][BN]
+    float *Sn = reinterpret_cast<float *>(Ws + 2 * WF);          // [2][CinP]: exp(alpha) | 1/(exp(beta)+1e-9)
+
+    int nwg = gridDim.x, orig = blockIdx.x;
+    int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+    int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    int nt = id % n_tiles;
+    int pt = id / n_tiles;
+    int unit = pt / tiles_per_unit;
+    int m0 = (pt - unit * tiles_per_unit) * BMB;
+    int n0 = nt * BN;
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+
+    const float *xu = a.x + (long)unit * a.x_us;
+    const int ncb = (a.Cin + BKB - 1) / BKB;
+    const int CinP = ncb * BKB;
+    const int nstage = ncb * a.ntaps;
+
+    if (a.sn_a) {
+        for (int i = tid; i < CinP; i += NTHB) {
+            Sn[i] = i < a.Cin ? a.sn_a[i] : 0.0f;
+            Sn[CinP + i] = i < a.Cin ? a.sn_ib[i] : 0.0f;
+        }
+        __syncthreads();
+    }
+
+    f32x16 acc[TN];
+#pragma unroll
+    for (int i = 0; i < TN; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][r] = 0.0f;
+
+    // ---- W staging: the packed tensor is [tap][cb][4 k-groups][NP rows] of 16-byte elements
+    const uint4 *wg = reinterpret_cast<const uint4 *>(a.wb);
+    uint4 w0 = make_uint4(0, 0, 0, 0), w1 = w0;
+    const int wq0 = tid / BN, wr0 = tid - wq0 * BN;
+    const int wq1 = (tid + NTHB) / BN, wr1 = tid + NTHB - wq1 * BN;
+#define W_LOAD(stage_)                                                                          \
+    {                                                                                           \
+        int cb_ = (stage_) / a.ntaps, tap_ = (stage_)-cb_ * a.ntaps;                            \
+        const uint4 *wp_ = wg + ((long)(tap_ * ncb + cb_) * 4) * a.NP + n0;                     \
+        if (WF >= NTHB || tid < WF) w0 = wp_[(long)wq0 * a.NP + wr0];                           \
+        if constexpr (WPT > 1) if (tid + NTHB < WF) w1 = wp_[(long)wq1 * a.NP + wr1];           \
+    }
+#define W_STORE(buf_)                                                                           \
+    {                                                                                           \
+        uint4 *ws_ = reinterpret_cast<uint4 *>(Ws) + (buf_)*WF + tid;                           \
+        if (WF >= NTHB || tid < WF) *ws_ = w0;                                                  \
+        if constexpr (WPT > 1) if (tid + NTHB < WF) ws_[NTHB] = w1;                             \
+    }
+
+    // ---- X staging: (k-group, position) pairs, three rounds of 512
+    f32x8 xa, xb, xc;
+    int kqa, kqb, kqc, ta, tb, tc;
+    {
+        int p0 = tid, p1 = tid + NTHB, p2 = tid + 2 * NTHB;
+        kqa = p0 / XW; ta = p0 - kqa * XW;
+        kqb = p1 / XW; tb = p1 - kqb * XW;
+        kqc = p2 / XW; tc = p2 - kqc * XW;
+    }
+    auto x_fetch1 = [&](int cb, int kq, int t) -> f32x8 {
+        f32x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = 0.0f;
+        int pos = m0 - HL + t;
+        if (kq < 4 && pos >= 0 && pos < a.Lin) {
+            int c0 = cb * BKB + kq * 8;
+            const float *xp = xu + (long)c0 * a.x_cs + pos;
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if (c0 + j < a.Cin) v[j] = xp[(long)j * a.x_cs];
+        }
+        return v;
+    };
+    auto x_commit1 = [&](int cb, int buf, int kq, int t, f32x8 v) {
+        if (kq >= 4) return;
+        if (a.sn_a) {
+            const float4 *sa = reinterpret_cast<const float4 *>(Sn + cb * BKB + kq * 8);
+            const float4 *sb = reinterpret_cast<const float4 *>(Sn + CinP + cb * BKB + kq * 8);
+            float4 a0 = sa[0], a1 = sa[1], b0 = sb[0], b1 = sb[1];
+            v[0] = snake_beta(v[0], a0.x, b0.x); v[1] = snake_beta(v[1], a0.y, b0.y);
+            v[2] = snake_beta(v[2], a0.z, b0.z); v[3] = snake_beta(v[3], a0.w, b0.w);
+            v[4] = snake_beta(v[4], a1.x, b1.x); v[5] = snake_beta(v[5], a1.y, b1.y);
+            v[6] = snake_beta(v[6], a1.z, b1.z); v[7] = snake_beta(v[7], a1.w, b1.w);
+        }
+        Xs[buf * 4 * XW + kq * XW + t] = pack8(v);
+    };
+#define X_FETCH(cb_) { xa = x_fetch1(cb_, kqa, ta); xb = x_fetch1(cb_, kqb, tb); xc = x_fetch1(cb_, kqc, tc); }
+#define X_COMMIT(cb_, buf_) { x_commit1(cb_, buf_, kqa, ta, xa); x_commit1(cb_, buf_, kqb, tb, xb); x_commit1(cb_, buf_, kqc, tc, xc); }
+
+    X_FETCH(0)
+    W_LOAD(0);
+    X_COMMIT(0, 0)
+    W_STORE(0);
+    for (int cb = 0; cb < ncb; cb++) {
+        const bool xnext = cb + 1 < ncb;
+        if (xnext) X_FETCH(cb + 1)
+        for (int tap = 0; tap < a.ntaps; tap++) {
+            const int st = cb * a.ntaps + tap;
+            if (st + 1 < nstage) W_LOAD(st + 1);
+            __syncthreads();
+            {
+                const bf16x8 *wsb = Ws + (st & 1) * WF + l31;
+                const bf16x8 *xsb = Xs + (cb & 1) * 4 * XW + wave * 32 + l31 + HL + a.shift0 + tap * a.shift_step;
+#pragma unroll
+                for (int ks = 0; ks < 2; ks++) {
+                    const int kq = ks * 2 + h;
+                    bf16x8 bv = xsb[kq * XW];
+                    bf16x8 av[TN];
+#pragma unroll
+                    for (int i = 0; i < TN; i++) av[i] = wsb[kq * BN + i * 32];
+#pragma unroll
+                    for (int i = 0; i < TN; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv, acc[i], 0, 0, 0);
+                }
+            }
+            if (st + 1 < nstage) W_STORE((st + 1) & 1);
+        }
+        if (xnext) X_COMMIT(cb + 1, (cb + 1) & 1)
+    }
+#undef X_FETCH
+#undef X_COMMIT
+#undef W_LOAD
+#undef W_STORE
+
+    if constexpr (FUSE) {
+        // H = snake2(acc + b1) -> bf16 B operands hb[i][g] (lane's registers 8g..8g+7 of tile i)
+        constexpr int W2N = 128 * TN;     // 16-byte elements per W2 tile: [2*TN k-steps][2 lane halves][32 rows]
+        const uint4 *w2g = reinterpret_cast<const uint4 *>(launder_after(a.wb2, acc[0][15]));
+        if (tid < W2N) w0 = w2g[tid];
+        if constexpr (W2N > NTHB) if (tid + NTHB < W2N) w1 = w2g[tid + NTHB];
+        bf16x8 hb[TN][2];
+#pragma unroll
+        for (int i = 0; i < TN; i++) {
+            const float *b1p = launder_after(a.bias, acc[i][15]), *s2a = launder_after(a.sn2_a, acc[i][15]),
+                        *s2b = launder_after(a.sn2_ib, acc[i][15]);
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                int n = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                acc[i][r] = snake_beta(acc[i][r] + b1p[n], s2a[n], s2b[n]);
+                if ((r & 3) == 3) {
+                    asm volatile("" : "+v"(acc[i][r - 3]), "+v"(acc[i][r - 2]), "+v"(acc[i][r - 1]), "+v"(acc[i][r]));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 2; g++)
+#pragma unroll
+                for (int j = 0; j < 8; j++) hb[i][g][j] = (__bf16)acc[i][8 * g + j];
+        }
+        float *yu = a.y + (long)unit * a.y_us;
+        const int m = m0 + wave * 32 + l31;
+        uint4 *w2s = reinterpret_cast<uint4 *>(smem_raw);
+        __syncthreads();                          // every wave is done with the main loop's tiles
+        if (tid < W2N) w2s[tid] = w0;
+        if constexpr (W2N > NTHB) if (tid + NTHB < W2N) w2s[tid + NTHB] = w1;
+        float dep2 = acc[TN - 1][15];
+#pragma unroll
+        for (int o = 0; o < TN; o++) {
+            if (o + 1 < TN) {
+                const uint4 *wq_ = reinterpret_cast<const uint4 *>(launder_after(a.wb2, dep2)) + (o + 1) * W2N;
+                if (tid < W2N) w0 = wq_[tid];
+                if constexpr (W2N > NTHB) if (tid + NTHB < W2N) w1 = wq_[tid + NTHB];
+            }
+            __syncthreads();
+            f32x16 acc2;
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc2[r] = 0.0f;
+            const bf16x8 *ws = reinterpret_cast<const bf16x8 *>(smem_raw) + (o & 1) * W2N + h * 32 + l31;
+#pragma unroll
+            for (int i = 0; i < TN; i++)
+#pragma unroll
+                for (int g = 0; g < 2; g++)
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ws[(i * 2 + g) * 64], hb[i][g], acc2, 0, 0, 0);
+            if (o + 1 < TN) {
+                uint4 *wd_ = w2s + ((o + 1) & 1) * W2N;
+                if (tid < W2N) wd_[tid] = w0;
+                if constexpr (W2N > NTHB) if (tid + NTHB < W2N) wd_[tid + NTHB] = w1;
+            }
+            dep2 = acc2[15];
+            const float *b2p = launder_after(a.bias2, acc2[15]);
+            const float *rup = launder_after(a.res, acc2[15]) + (long)unit * a.y_us;
+            const float *pa = launder_after(a.psn_a, acc2[15]), *pb = launder_after(a.psn_ib, acc2[15]);
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                int n = o * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (n >= a.N || m >= a.M) continue;
+                long oo = (long)n * a.y_cs + m;
+                float v = rup[oo] + (acc2[r] + b2p[n]);
+                if (pa) v = snake_beta(v, pa[n], pb[n]);
+                yu[oo] = v;
+            }
+        }
+        return;
+    }
+
+    // epilogue (fp32): bias, activation, per-channel scale, residual, optional SnakeBeta, store
+    float *yu = a.y + (long)unit * a.y_us;
+    const float *ru0 = launder_after(a.res, acc[TN - 1][15]);
+    const float *ru = ru0 ? ru0 + (long)unit * a.y_us : nullptr;
+    const float *bp = launder_after(a.bias, acc[TN - 1][15]), *scp = launder_after(a.rscale, acc[TN - 1][15]);
+    const float *pa = launder_after(a.psn_a, acc[TN - 1][15]), *pb = launder_after(a.psn_ib, acc[TN - 1][15]);
+    float *y2u0 = launder_after(a.y2, acc[TN - 1][15]);
+    float *y2u = y2u0 ? y2u0 + (long)unit * a.y_us : nullptr;
+    const int m = m0 + wave * 32 + l31;
+#pragma unroll
+    for (int i = 0; i < TN; i++) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            int n = n0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (n >= a.N || m >= a.M) continue;
+            int co = n, ph = 0;
+            if (a.S > 1) { co = n / a.S; ph = n - co * a.S; }
+            float bb = bp ? bp[co] : 0.0f;
+            float sc = scp ? scp[co] : 1.0f;
+            float v = acc[i][r] + bb;
+            if (a.act == ACT_GELU) v = gelu_erf(v);
+            if (scp) v = v * sc;
+            long o = (long)co * a.y_cs + (long)m * a.S + ph;
+            if (ru) v = ru[o] + v;
+            if (a.act == ACT_CLAMP1) v = fminf(fmaxf(v, -1.0f), 1.0f);
+            if (pa) {
+                float sv = snake_beta(v, pa[co], pb[co]);
+                if (y2u) { yu[o] = v; y2u[o] = sv; } else yu[o] = sv;
+            } else {
+                yu[o] = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+size_t conv_gemm_bf16_lds_bytes(const ConvGemmArgs &a) {
+    int HL, XW;
+    detail::conv_gemm_geometry(a, HL, XW);
+    const int tn = detail::conv_gemm_launch_tn(a);
+    const int CinP = (a.Cin + BKB - 1) / BKB * BKB;
+    size_t b = 16 * (2 * 4 * (size_t)XW + 2 * 4 * (size_t)32 * tn) + (a.sn_a ? 2 * sizeof(float) * CinP : 0);
+    if (a.wb2) b = b > 2 * 16 * (size_t)128 * tn ? b : 2 * 16 * (size_t)128 * tn;
+    return b;
+}
+
+const char *conv_gemm_bf16_kernel_name(const ConvGemmArgs &a) {
+    static char names[2][8][48];
+    int tn = detail::conv_gemm_launch_tn(a);
+    int fuse = a.wb2 ? 1 : 0;
+    char *n = names[fuse][tn & 7];
+    if (!n[0]) snprintf(n, 48, "conv_gemm_bf16_kernel<%d,%s>", tn, fuse ? "true" : "false");
+    return n;
+}
+
+template <int TN, bool FUSE>
+static hipError_t launch_one_bf16(const ConvGemmArgs &a, int HL, int XW, int tiles_per_unit, int n_tiles, long grid,
+                                  size_t lds, hipStream_t s) {
+    static bool done[64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64 && !done[dev]) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_gemm_bf16_kernel<TN, FUSE>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        done[dev] = true;
+    }
+    hipLaunchKernelGGL((conv_gemm_bf16_kernel<TN, FUSE>), dim3((unsigned)grid), dim3(NTHB), lds, s, a, HL, XW,
+                       tiles_per_unit, n_tiles);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv_gemm_bf16(const ConvGemmArgs &a, hipStream_t s) {
+    int HL, XW;
+    detail::conv_gemm_geometry(a, HL, XW);
+    if (a.M <= 0 || a.units <= 0) return hipSuccess;
+    // host-side shape checks: what the kernel's staging loops and vector accesses assume
+    if (!a.wb || (a.NP % (32 * a.TN)) || a.NP < a.N || a.TN < 1 || a.TN > 4 || ((uintptr_t)a.wb & 15) || a.ntaps < 1 ||
+        a.S < 1 || 4 * XW > 3 * NTHB)
+        return hipErrorInvalidValue;
+    const int tn = detail::conv_gemm_launch_tn(a);
+    if (a.y2 && (!a.psn_a || !a.psn_ib || a.wb2)) return hipErrorInvalidValue;
+    if (a.wb2 && (a.S != 1 || a.NP != 32 * tn || (a.N + 31) / 32 != tn || tn == 5 || tn > 6 || !a.res || !a.sn2_a ||
+                  !a.sn2_ib || !a.bias || !a.bias2 || ((uintptr_t)a.wb2 & 15)))
+        return hipErrorInvalidValue;
+    int tiles_per_unit = (a.M + BMB - 1) / BMB;
+    int n_tiles = a.NP / (32 * tn);
+    long grid = (long)tiles_per_unit * a.units * n_tiles;
+    if (grid > 0x7fffffffL) return hipErrorInvalidValue;
+    size_t lds = conv_gemm_bf16_lds_bytes(a);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+#define GO(TN_, F_) return launch_one_bf16<TN_, F_>(a, HL, XW, tiles_per_unit, n_tiles, grid, lds, s)
+    if (a.wb2) {
+        switch (tn) {
+            case 1: GO(1, true);
+            case 2: GO(2, true);
+            case 3: GO(3, true);
+            case 4: GO(4, true);
+            default: GO(6, true);
+        }
+    }
+    switch (tn) {
+        case 1: GO(1, false);
+        case 2: GO(2, false);
+        case 3: GO(3, false);
+        default: GO(4, false);
+    }
+#undef GO
+}
+
+}  // namespace hipvoc

@@ -1,0 +1,132 @@
+"""GPU tests of the bf16 conv-GEMM mode (HIPVOC_DTYPE_BF16, BASELINE configs[4]) through the C ABI.
+
+The mode rounds the operands of every conv / linear / transposed conv to bf16 (nearest even) and accumulates
+in fp32; RVQ, norms, attention, SnakeBeta, residual adds and the final C->1 conv stay fp32.  Two checkers:
+  * the oracle in its bf16-emulating mode (oracle/voc_oracle.c, bf16_gemm=1: same rounding points, fp32
+    products and sums): pins the arithmetic -- the first GEMM stages agree to fp32 round-off, later stages only
+    differ through rounding-boundary flips (a 1e-7 difference before a bf16 rounding becomes a 4e-3 one after);
+  * the fp32 oracle: the STATED TOLERANCE of the mode, separate from the fp32 gates (1e-3 / 60 dB):
+        waveform SNR >= 30 dB and max-abs error <= 3e-2 of full scale
+    (measured on the seeded random-weight full model: 35.9 dB / 1.2e-2; SURVEY.md 8d proposed 35 dB / 2e-2 "to be
+    fixed after first measurement").  Parity vs the shipped ONNX graph stays unpinned.
+"""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+from conftest import oracle_for, snr_db, weights_for
+
+pytestmark = pytest.mark.gpu
+
+BF16 = 1
+WAV_SNR_DB = 30.0
+WAV_MAX_ABS = 3e-2
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _torch_hip_first():
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.init()
+    yield
+
+
+_VOC = {}
+_OB = {}
+
+
+def voc_bf16(pkg, synth, cfg_name, unit):
+    key = (cfg_name, unit)
+    if key not in _VOC:
+        cfg = getattr(synth, cfg_name)
+        path = os.path.join(tempfile.gettempdir(), f"hipvoc_test_{cfg_name}_0.safetensors")
+        if not os.path.exists(path):
+            synth.save_safetensors(path, weights_for(synth, cfg_name, 0), cfg.metadata())
+        _VOC[key] = pkg.HipVocoder.load(path, device=0, unit_frames=unit, dtype=BF16)
+    return _VOC[key]
+
+
+def oracle_bf16(vo, synth, cfg_name):
+    if cfg_name not in _OB:
+        cfg = getattr(synth, cfg_name)
+        md = {k: float(v) for k, v in cfg.metadata().items()}
+        md["bf16_gemm"] = 1.0
+        _OB[cfg_name] = vo.Oracle(weights_for(synth, cfg_name, 0), md)
+    return _OB[cfg_name]
+
+
+@pytest.mark.parametrize("cfg_name,T", [("SMALL", 8), ("ODD", 9), ("FULL", 3)])
+def test_bf16_dequant_stays_bit_exact_and_first_gemms_match_emulation(pkg, synth, vo, cfg_name, T):
+    cfg = getattr(synth, cfg_name)
+    v = voc_bf16(pkg, synth, cfg_name, T)
+    ob = oracle_bf16(vo, synth, cfg_name)
+    codes = synth.make_codes(T, 21 + T, cfg)
+    for s in (1000, 0):          # raw dequant sums, projected dequant output: fp32 in every mode
+        ref = ob.stage(codes, s)
+        got = v.stage(codes, s, ref.size + 8)
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), s
+    ref = ob.stage(codes, 1)     # pre_conv: the first bf16 GEMM, identical inputs on both sides
+    got = v.stage(codes, 1, ref.size + 8)
+    assert np.abs(got - ref).max() <= 1e-5
+
+
+@pytest.mark.parametrize("cfg_name,T", [("SMALL", 8), ("ODD", 9), ("FULL", 3)])
+def test_bf16_every_stage_tracks_the_emulation(pkg, synth, vo, cfg_name, T):
+    """Every stage is at least as close to the fp32 oracle as the bf16-emulating oracle is (3 dB slack), and
+    within 30 dB of the emulation itself (flips only)."""
+    cfg = getattr(synth, cfg_name)
+    v = voc_bf16(pkg, synth, cfg_name, T)
+    ob = oracle_bf16(vo, synth, cfg_name)
+    o32 = oracle_for(vo, synth, cfg_name, 0)
+    codes = synth.make_codes(T, 21 + T, cfg)
+    assert v.n_stages == ob.n_stages
+    for s in range(1, v.n_stages):
+        rb = ob.stage(codes, s)
+        r32 = o32.stage(codes, s)
+        got = v.stage(codes, s, rb.size + 8)
+        assert got.shape == rb.shape
+        assert snr_db(rb, got) >= 30.0, (s, snr_db(rb, got))
+        assert snr_db(r32, got) >= snr_db(r32, rb) - 3.0, (s, snr_db(r32, got), snr_db(r32, rb))
+
+
+def test_bf16_full_utterance_within_stated_tolerance(pkg, synth, vo):
+    """configs[1]'s utterance (125 frames, full model) in bf16 mode against the fp32 oracle."""
+    cfg = synth.FULL
+    v = voc_bf16(pkg, synth, "FULL", 64)
+    o32 = oracle_for(vo, synth, "FULL", 0)
+    codes = synth.make_codes(125, 1000, cfg)
+    got = v.synthesize(codes)
+    ref = o32.synthesize(codes, 64)
+    assert got.size == ref.size
+    err = np.abs(got - ref).max()
+    snr = snr_db(ref, got)
+    assert err <= WAV_MAX_ABS, err
+    assert snr >= WAV_SNR_DB, snr
+
+
+def test_bf16_chunk_loop_ragged_and_batch_bitwise(pkg, synth, vo):
+    """Chunk loop / padding / truncation are mode-independent host logic; a batch equals separate calls bit for bit."""
+    cfg = synth.SMALL
+    v = voc_bf16(pkg, synth, "SMALL", 4)
+    o32 = oracle_for(vo, synth, "SMALL", 0)
+    seqs = [synth.make_codes(n, 50 + n, cfg) for n in (1, 4, 5, 10, 3)]
+    outs = v.synthesize_batch(seqs)
+    for c, got in zip(seqs, outs):
+        one = v.synthesize(c)
+        assert np.array_equal(one.view(np.uint32), got.view(np.uint32))
+        ref = o32.synthesize(c, 4)
+        assert got.size == ref.size
+        assert snr_db(ref, got) >= WAV_SNR_DB
+        assert np.abs(got - ref).max() <= WAV_MAX_ABS
+    assert v.synthesize(np.zeros((0, 16), dtype=np.int64)).size == 0
+
+
+def test_bf16_deterministic(pkg, synth):
+    cfg = synth.FULL
+    v = voc_bf16(pkg, synth, "FULL", 64)
+    codes = synth.make_codes(64, 5, cfg)
+    a = v.run(codes)
+    b = v.run(codes)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
