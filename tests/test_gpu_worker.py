@@ -1,0 +1,85 @@
+"""hipvoc-worker (csrc/worker_main.cpp): the reference's `qwen3-tts worker -r vocoder` as a standalone process,
+driven over TCP by the mirror of src/worker_client.rs (qwen3-tts_amd/wire.py), checked against the oracle."""
+import os
+import struct
+import subprocess
+import tempfile
+
+import msgpack
+import numpy as np
+import pytest
+
+from conftest import ROOT, oracle_for, weights_for
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def worker(synth):
+    cfg = synth.SMALL
+    path = os.path.join(tempfile.gettempdir(), "hipvoc_test_SMALL_0.safetensors")
+    if not os.path.exists(path):
+        synth.save_safetensors(path, weights_for(synth, "SMALL", 0), cfg.metadata())
+    exe = os.path.join(ROOT, "qwen3-tts_amd", "hipvoc-worker")
+    assert os.path.exists(exe), "hipvoc-worker not built (make -C qwen3-tts_amd/csrc)"
+    p = subprocess.Popen([exe, "-r", "vocoder", "-m", path, "-b", "127.0.0.1:0", "--unit-frames", "4"],
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    line = p.stdout.readline()
+    assert "listening on" in line, line + p.stdout.read()
+    port = int(line.split("listening on ")[1].split()[0].rsplit(":", 1)[1])
+    yield port
+    p.kill()
+    p.wait()
+
+
+def test_worker_ping_init_vocode_matches_oracle(pkg, synth, vo, worker):
+    wire = pkg.wire
+    c = wire.WorkerClient("127.0.0.1", worker)
+    assert c.ping()
+    assert c.call(wire.request_init("vocoder", "/nonexistent")) == "Init"
+    o = oracle_for(vo, synth, "SMALL", 0)
+    for n in (1, 4, 10, 9):
+        codes = synth.make_codes(n, 70 + n, synth.SMALL)
+        pcm = c.vocode(codes)
+        ref = o.synthesize(codes, 4)
+        assert pcm.size == ref.size
+        ref_pcm = vo.pcm16(ref)
+        # the float waveform is within 1e-3 of the oracle's, so PCM is within 33 LSB; in practice 0-1
+        assert np.abs(pcm.astype(np.int32) - ref_pcm.astype(np.int32)).max() <= 33
+    # same connection keeps serving after an error (mod.rs:246-258): a talker request, then bad codes
+    with pytest.raises(wire.WorkerError):
+        c.call(msgpack.packb({"TalkerStep": [None, 0.9, 1.05, 0.0]}))
+    bad = synth.make_codes(4, 1, synth.SMALL)
+    bad[2, 3] = synth.SMALL.codebook_size
+    with pytest.raises(wire.WorkerError):
+        c.vocode(bad)
+    with pytest.raises(wire.WorkerError):          # fewer code bytes than n_tokens*16
+        c.call(wire.request_vocode(synth.make_codes(2, 1, synth.SMALL), n_tokens=3))
+    assert c.ping()
+    c.close()
+
+
+def test_worker_batch_equals_single_requests_and_two_clients(pkg, synth, worker):
+    wire = pkg.wire
+    a = wire.WorkerClient("127.0.0.1", worker)
+    b = wire.WorkerClient("127.0.0.1", worker)
+    seqs = [synth.make_codes(n, 90 + n, synth.SMALL) for n in (3, 8, 1, 5)]
+    single = [(a if i % 2 else b).vocode(s) for i, s in enumerate(seqs)]
+    batch = a.vocode_batch(seqs)
+    for x, y in zip(single, batch):
+        assert np.array_equal(x, y)
+    assert a.vocode_batch([]) == []
+    a.close()
+    b.close()
+
+
+def test_worker_rejects_oversize_frame_then_closes(pkg, worker):
+    wire = pkg.wire
+    c = wire.WorkerClient("127.0.0.1", worker)
+    c.sock.sendall(struct.pack(">I", wire.MAX_MESSAGE + 1))
+    status, data, err = c.read_response()
+    assert status == "error" and "too large" in err
+    c.close()
+    d = wire.WorkerClient("127.0.0.1", worker)     # the worker itself keeps running
+    assert d.ping()
+    d.close()

@@ -11,15 +11,17 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_library_exports_every_declared_symbol(pkg):
-    hdr = open(os.path.join(ROOT, "include", "hipvoc.h")).read()
+@pytest.mark.parametrize("header,exports", [("hipvoc.h", "hipvoc.EXPORTS"), ("hipvoc_wire.h", "wire.WIRE_EXPORTS")])
+def test_library_exports_every_declared_symbol(pkg, header, exports):
+    hdr = open(os.path.join(ROOT, "include", header)).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     declared = set(re.findall(r"\b(hipvoc_[a-z0-9_]+)\s*\(", hdr))
     assert declared, "no declarations parsed"
     lib = pkg.load_library()
     for sym in sorted(declared):
-        assert hasattr(lib, sym), f"{sym} declared in include/hipvoc.h but not exported"
-    assert declared == set(pkg.hipvoc.EXPORTS)
+        assert hasattr(lib, sym), f"{sym} declared in include/{header} but not exported"
+    mod, name = exports.split(".")
+    assert declared == set(getattr(getattr(pkg, mod), name))
 
 
 def test_no_cpu_fallback(pkg, tmp_path):
