@@ -165,6 +165,28 @@ def main():
                     "avg_launch_ms": round(kd["ms"] / kd["launches"], 4), "launches_per_pass": kd["launches"],
                     "units_per_pass": G, "share_of_pass_time": round(kd["ms"] / sum(k["ms"] for k in kernels.values()), 3)}
 
+    # --- HBM-bound kernels: algorithmic bytes (from the tensor shapes) / live-measured time, against 8 TB/s
+    hbm = {}
+    if rank == 0 and kernels:
+        G = voc.group_units
+        L = T
+        dw_bytes = 0
+        for r in cfg.upsampling_ratios:
+            L *= r
+            dw_bytes += 2 * cfg.latent_dim * L * 4 * G                 # x in, normalised y out
+        Lw = voc.unit_samples
+        alg = {
+            "final_conv_kernel<7>": G * (cfg.decoder_dim // 16 * Lw + Lw) * 4,   # C=96 activations in, 1 channel out
+            "dwconv_ln_kernel": dw_bytes,
+            "rmsnorm_kernel": (2 * cfg.num_hidden_layers + 1) * 2 * cfg.hidden_size * G * T * 4,
+            "swiglu_kernel": cfg.num_hidden_layers * 3 * cfg.intermediate_size * G * T * 4,
+        }
+        for k, b in alg.items():
+            if k in kernels and kernels[k]["ms"] > 0:
+                gbs = b / (kernels[k]["ms"] * 1e-3) / 1e9
+                hbm[k] = {"algorithmic_MB_per_pass": round(b / 1e6, 1), "achieved_GBps": round(gbs, 1),
+                          "frac_of_8TBps": round(gbs / 8000.0, 3)}
+
     # --- CPU baseline + parity spot check (rank 0, N=1 only)
     cpu = None
     parity = None
@@ -181,6 +203,14 @@ def main():
         cpu = {"value": round(kept / cdt, 3), "unit": "audio-sec/sec", "cores": cores, "kind": "port",
                "sample": f"{n_sample} reference units (64-frame, incl. one padded 61-frame tail) of utterances 0-1 "
                          f"of the same batch, oracle/voc_oracle.c with {cores} OpenMP threads, {cdt:.1f} s"}
+        # the reference's own session uses intra_threads = clamp(nproc, 1, 4) (src/worker/vocoder.rs:138-141)
+        vo.set_threads(4)
+        t = time.perf_counter()
+        oracle.run_unit(codes[0])
+        cdt4 = time.perf_counter() - t
+        vo.set_threads(0)
+        cpu["value_4_threads"] = round(T * 1920 / 24000.0 / cdt4, 3)
+        cpu["sample_4_threads"] = f"1 full reference unit, 4 OpenMP threads, {cdt4:.1f} s"
         got = d_out[:n_sample].cpu().numpy()[:, : voc.unit_samples]
         err = max(float(np.abs(got[i] - refs[i]).max()) for i in range(n_sample))
         num = sum(float(np.sum(refs[i].astype(np.float64) ** 2)) for i in range(n_sample))
@@ -204,7 +234,7 @@ def main():
             "gflop_per_unit": round(unit_flops / 1e9, 2),
             "achieved_tflops_whole_path": round(world * n_units * args.steps * unit_flops / dt / 1e12, 2),
             "single_utterance_latency_ms": None if lat_ms is None else round(lat_ms, 2),
-            "roofline": roofline, "cpu_baseline": cpu, "parity_vs_oracle": parity,
+            "roofline": roofline, "cpu_baseline": cpu, "parity_vs_oracle": parity, "hbm_bound_kernels": hbm,
             "kernels": {k: {"ms_per_pass": round(v["ms"], 3), "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2),
                             "launches": v["launches"]} for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])},
         }

@@ -165,8 +165,24 @@ def make_codes(n_frames: int, seed: int, cfg: DecoderConfig = FULL) -> np.ndarra
                                                 dtype=np.int64)
 
 
-def save_safetensors(path: str, tensors: Dict[str, np.ndarray], metadata: Dict[str, str] | None = None) -> None:
-    """Minimal safetensors writer (8-byte LE header length, JSON header, raw LE data)."""
+def to_bf16_bits(a: np.ndarray) -> np.ndarray:
+    """fp32 -> bf16 bit patterns (uint16), round to nearest even."""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+
+def from_bf16_bits(b: np.ndarray) -> np.ndarray:
+    return (b.astype(np.uint32) << 16).view(np.float32)
+
+
+def save_safetensors(path: str, tensors: Dict[str, np.ndarray], metadata: Dict[str, str] | None = None,
+                     dtype: str = "F32") -> None:
+    """Minimal safetensors writer (8-byte LE header length, JSON header, raw LE data).  dtype: the storage
+    type of every tensor, "F32", "F16" or "BF16" (what upstream checkpoints come in)."""
+    enc = {"F32": lambda a: np.ascontiguousarray(a, dtype="<f4").tobytes(),
+           "F16": lambda a: np.ascontiguousarray(a, dtype=np.float32).astype("<f2").tobytes(),
+           "BF16": lambda a: to_bf16_bits(a).astype("<u2").tobytes()}[dtype]
+    item = {"F32": 4, "F16": 2, "BF16": 2}[dtype]
     header = {}
     if metadata:
         header["__metadata__"] = dict(metadata)
@@ -174,15 +190,15 @@ def save_safetensors(path: str, tensors: Dict[str, np.ndarray], metadata: Dict[s
     names = sorted(tensors)
     for n in names:
         a = np.ascontiguousarray(tensors[n], dtype=np.float32)
-        header[n] = {"dtype": "F32", "shape": list(a.shape), "data_offsets": [off, off + a.nbytes]}
-        off += a.nbytes
+        header[n] = {"dtype": dtype, "shape": list(a.shape), "data_offsets": [off, off + a.size * item]}
+        off += a.size * item
     hj = json.dumps(header, separators=(",", ":")).encode()
     hj += b" " * ((8 - len(hj) % 8) % 8)
     with open(path, "wb") as f:
         f.write(struct.pack("<Q", len(hj)))
         f.write(hj)
         for n in names:
-            f.write(np.ascontiguousarray(tensors[n], dtype=np.float32).tobytes())
+            f.write(enc(tensors[n]))
 
 
 def config_dict(cfg: DecoderConfig) -> dict:

@@ -209,6 +209,32 @@ def test_window_binds_when_unit_is_longer_than_window(pkg, synth, vo):
     assert snr_db(ref, got) >= WAV_SNR_DB
 
 
+@pytest.mark.parametrize("store", ["F16", "BF16"])
+def test_half_precision_checkpoints_load_like_their_fp32_values(pkg, synth, vo, store, tmp_path):
+    """Upstream checkpoints come as F32, F16 or BF16 (csrc/safetensors.cpp converts on load); the decode is then the
+    fp32 decode of exactly those rounded values."""
+    cfg = synth.SMALL
+    W = weights_for(synth, "SMALL", 0)
+    if store == "F16":
+        Wr = {k: v.astype(np.float16).astype(np.float32) for k, v in W.items()}
+    else:
+        Wr = {k: synth.from_bf16_bits(synth.to_bf16_bits(v)).reshape(v.shape) for k, v in W.items()}
+    path = str(tmp_path / f"small_{store}.safetensors")
+    synth.save_safetensors(path, W, cfg.metadata(), dtype=store)
+    assert os.path.getsize(path) < 0.6 * sum(v.size * 4 for v in W.values())
+    v = pkg.HipVocoder.load(path, device=0, unit_frames=6)
+    o = vo.Oracle(Wr, {k: float(x) for k, x in cfg.metadata().items()})
+    codes = synth.make_codes(6, 77, cfg)
+    sums_ref = o.stage(codes, 1000)
+    sums = v.stage(codes, 1000, sums_ref.size + 8)
+    assert np.array_equal(sums.view(np.uint32), sums_ref.view(np.uint32))
+    ref = o.run_unit(codes)
+    got = v.run(codes)
+    assert np.abs(got - ref).max() <= WAV_MAX_ABS
+    assert snr_db(ref, got) >= WAV_SNR_DB
+    v.close()
+
+
 # ------------------------------------------------------------------------------------ full size
 def test_full_single_utterance_matches_oracle(pkg, synth, vo):
     """BASELINE configs[1]: one 10 s utterance (125 frames -> units of 64 + 61), fp32, full model."""
