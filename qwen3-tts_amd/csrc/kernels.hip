@@ -154,8 +154,8 @@ __global__ __launch_bounds__(NTH, (FUSE && TN > 4) ? 2 : 4) void conv_gemm_kerne
         if (xnext) X_FETCH(cb + 1)
         for (int tap = 0; tap < a.ntaps; tap++) {
             const int st = cb * a.ntaps + tap;
-            if (st + 1 < nstage) W_LOAD(st + 1);
-            __syncthreads();              // Ws[st&1] (and, at tap 0, the committed Xs[cb&1]) are visible
+            if (st + 1 < nstage && !(a.dbg & 2)) W_LOAD(st + 1);
+            if (!(a.dbg & 4)) __syncthreads();   // Ws[st&1] (and, at tap 0, the committed Xs[cb&1]) are visible
             {
                 const float *ws = Ws + (st & 1) * (BK * BN) + l31;
                 const float *xs = smem + (cb & 1) * xtile + wave * 32 + l31 + HL + a.shift0 + tap * a.shift_step;
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(NTH, (FUSE && TN > 4) ? 2 : 4) void conv_gemm_kerne
                     for (int i = 0; i < TN; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv, acc[i], 0, 0, 0);
                 }
             }
-            if (st + 1 < nstage) W_STORE((st + 1) & 1);
+            if (st + 1 < nstage && !(a.dbg & 2)) W_STORE((st + 1) & 1);
         }
         // Xs[(cb+1)&1] was last read during cb-1; every wave has passed a later barrier since
         if (xnext) X_COMMIT(cb + 1, (cb + 1) & 1)
@@ -178,6 +178,17 @@ __global__ __launch_bounds__(NTH, (FUSE && TN > 4) ? 2 : 4) void conv_gemm_kerne
 #undef X_FETCH
 #undef X_COMMIT
 
+    if (a.dbg & 8) {   // timing-only: main loop alone (one never-taken store keeps the MFMAs alive)
+        if (a.dbg & 64) {
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < TN; i++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) t += acc[i][r];
+            a.y[tid] = t;
+        }
+        return;
+    }
     if constexpr (FUSE) {
         // H = snake2(acc + b1), in place.  Register r of tile i is channel i*32 + (r&3) + 8*(r>>2) + 4*h.
         // bias / snake vectors are zero-padded by the loader, so padded rows stay exactly 0.
@@ -240,6 +251,16 @@ __global__ __launch_bounds__(NTH, (FUSE && TN > 4) ? 2 : 4) void conv_gemm_kerne
         for (int o = 0; o < TN; o++) {
             if (o + 1 < TN) W2_FETCH(o + 1)
             __syncthreads();                      // tile o visible; tile o-1's readers are past
+            // this tile's residual is fetched before its product, so HBM latency hides under the MFMAs
+            float resv[16];
+            {
+                const float *rup = launder_after(a.res, dep2) + (long)unit * a.y_us;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    int n = o * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    resv[r] = (n < a.N && m < a.M) ? rup[(long)n * a.y_cs + m] : 0.0f;
+                }
+            }
             f32x16 acc2;
 #pragma unroll
             for (int r = 0; r < 16; r++) acc2[r] = 0.0f;
@@ -258,14 +279,13 @@ __global__ __launch_bounds__(NTH, (FUSE && TN > 4) ? 2 : 4) void conv_gemm_kerne
             dep2 = acc2[15];
             // + b2 + residual x, store this 32-row tile
             const float *b2p = launder_after(a.bias2, acc2[15]);
-            const float *rup = launder_after(a.res, acc2[15]) + (long)unit * a.y_us;
             const float *pa = launder_after(a.psn_a, acc2[15]), *pb = launder_after(a.psn_ib, acc2[15]);
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 int n = o * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (n >= a.N || m >= a.M) continue;
                 long oo = (long)n * a.y_cs + m;
-                float v = rup[oo] + (acc2[r] + b2p[n]);
+                float v = resv[r] + (acc2[r] + b2p[n]);
                 if (pa) v = snake_beta(v, pa[n], pb[n]);
                 yu[oo] = v;
             }
@@ -380,7 +400,7 @@ static hipError_t conv_gemm_launch_one(const ConvGemmArgs &a, int HL, int XW, in
 hipError_t launch_conv_gemm(const ConvGemmArgs &a_in, hipStream_t s) {
     if (a_in.wb) return launch_conv_gemm_bf16(a_in, s);
     ConvGemmArgs a = a_in;
-    {   // timing-only ablation switch (HIPVOC_DBG bit0: stage the activation tile only once).  Results are
+    {   // timing-only ablation switch (HIPVOC_DBG bit0: stage the activation tile only once; bit1: the weight tile only once; bit2: no barriers; bit3: main loop only).  Results are
         // WRONG with it set; never set in production.
         static int dbg = -1;
         if (dbg < 0) { const char *e = getenv("HIPVOC_DBG"); dbg = e ? atoi(e) : 0; }

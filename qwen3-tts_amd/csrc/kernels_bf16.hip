@@ -208,6 +208,15 @@ __global__ __launch_bounds__(NTHB, (TN > 4) ? 2 : 4) void conv_gemm_bf16_kernel(
                 if constexpr (W2N > NTHB) if (tid + NTHB < W2N) w1 = wq_[tid + NTHB];
             }
             __syncthreads();
+            float resv[16];   // this tile's residual, in flight during its product
+            {
+                const float *rup = launder_after(a.res, dep2) + (long)unit * a.y_us;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    int n = o * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    resv[r] = (n < a.N && m < a.M) ? rup[(long)n * a.y_cs + m] : 0.0f;
+                }
+            }
             f32x16 acc2;
 #pragma unroll
             for (int r = 0; r < 16; r++) acc2[r] = 0.0f;
@@ -224,14 +233,13 @@ __global__ __launch_bounds__(NTHB, (TN > 4) ? 2 : 4) void conv_gemm_bf16_kernel(
             }
             dep2 = acc2[15];
             const float *b2p = launder_after(a.bias2, acc2[15]);
-            const float *rup = launder_after(a.res, acc2[15]) + (long)unit * a.y_us;
             const float *pa = launder_after(a.psn_a, acc2[15]), *pb = launder_after(a.psn_ib, acc2[15]);
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 int n = o * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (n >= a.N || m >= a.M) continue;
                 long oo = (long)n * a.y_cs + m;
-                float v = rup[oo] + (acc2[r] + b2p[n]);
+                float v = resv[r] + (acc2[r] + b2p[n]);
                 if (pa) v = snake_beta(v, pa[n], pb[n]);
                 yu[oo] = v;
             }
