@@ -53,7 +53,7 @@ hipError_t launch_conv_gemm_bf16(const ConvGemmArgs &a, hipStream_t s);
 const char *conv_gemm_bf16_kernel_name(const ConvGemmArgs &a);
 size_t conv_gemm_bf16_lds_bytes(const ConvGemmArgs &a);
 namespace detail {
-void conv_gemm_geometry(const ConvGemmArgs &a, int &HL, int &XW);   // halo (left, multiple of 4) and LDS tile width
+void conv_gemm_geometry(const ConvGemmArgs &a, int &HL, int &XW, int bm = 256);   // halo (left, multiple of 4) and LDS tile width for bm positions
 int conv_gemm_launch_tn(const ConvGemmArgs &a);                     // row-tile height actually launched
 }
 // kernel symbol family actually launched for these args (profiling labels)

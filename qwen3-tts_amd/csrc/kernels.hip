@@ -34,16 +34,16 @@ static constexpr int BK = 16;    // input channels per K stage
 //   (Measured on MI355X, G=32: staging X without the prefetch cost 11-13% of conv7 time and 26% of the
 //    2-tap transposed convs; weights straight from L2 instead of LDS were 15% slower.)
 // -------------------------------------------------------------------------------------------------
-static constexpr int NWV = 8;                 // waves per workgroup
-static constexpr int NTH = NWV * 64;
 
-template <int TN, bool FUSE>
-__global__ __launch_bounds__(NTH, (FUSE && TN > 4) ? 2 : 4) void conv_gemm_kernel(ConvGemmArgs a, int HL, int XW, int tiles_per_unit,
-                                                                       int n_tiles) {
+template <int TN, bool FUSE, int NW>
+__global__ __launch_bounds__(NW * 64, (FUSE && TN > 4) ? 2 : 4) void conv_gemm_kernel(ConvGemmArgs a, int HL, int XW, int tiles_per_unit,
+                                                                           int n_tiles) {
+    constexpr int NTH = NW * 64;                     // NW waves; the workgroup covers BM = 32*NW positions
+    constexpr int BM = NW * 32;
     constexpr int BN = TN * 32;
     constexpr int WF4 = 4 * BN;                      // float4 per W tile [BK][BN]
-    constexpr int WPT = (WF4 + NTH - 1) / NTH;       // float4 per thread (1 for TN <= 4, 2 for TN = 6)
-    static_assert(WPT <= 2, "W staging registers");
+    constexpr int WPT = (WF4 + NTH - 1) / NTH;       // float4 per thread
+    static_assert(WPT <= 3, "W staging registers");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int xtile = BK * XW;
     float *Ws = smem + 2 * xtile;                    // [2][BK][BN] after Xs[2][BK][XW]
@@ -75,14 +75,16 @@ __global__ __launch_bounds__(NTH, (FUSE && TN > 4) ? 2 : 4) void conv_gemm_kerne
         for (int r = 0; r < 16; r++) acc[i][r] = 0.0f;
 
     // ---- W staging through named registers
-    float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f), w1 = w0;
+    float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f), w1 = w0, wq2 = w0;
     const int wk0 = tid / (BN / 4), wc0 = (tid - wk0 * (BN / 4)) * 4;
     const int wk1 = (tid + NTH) / (BN / 4), wc1 = (tid + NTH - wk1 * (BN / 4)) * 4;
+    const int wk2 = (tid + 2 * NTH) / (BN / 4), wc2 = (tid + 2 * NTH - wk2 * (BN / 4)) * 4;
     // tile = BK rows starting at wp_ (row stride ld_), columns n0..n0+BN
 #define W_LOAD_FROM(wp_, ld_)                                                                              \
     {                                                                                                      \
         if (WF4 >= NTH || tid < WF4) w0 = *reinterpret_cast<const float4 *>((wp_) + (long)wk0 * (ld_) + wc0); \
         if constexpr (WPT > 1) if (WF4 >= 2 * NTH || tid + NTH < WF4) w1 = *reinterpret_cast<const float4 *>((wp_) + (long)wk1 * (ld_) + wc1); \
+        if constexpr (WPT > 2) if (WF4 >= 3 * NTH || tid + 2 * NTH < WF4) wq2 = *reinterpret_cast<const float4 *>((wp_) + (long)wk2 * (ld_) + wc2); \
     }
 #define W_LOAD(stage_)                                                                             \
     {                                                                                              \
@@ -95,6 +97,7 @@ __global__ __launch_bounds__(NTH, (FUSE && TN > 4) ? 2 : 4) void conv_gemm_kerne
         float *ws_ = Ws + (buf_) * (BK * BN) + tid * 4;                                            \
         if (WF4 >= NTH || tid < WF4) *reinterpret_cast<float4 *>(ws_) = w0;                        \
         if constexpr (WPT > 1) if (WF4 >= 2 * NTH || tid + NTH < WF4) *reinterpret_cast<float4 *>(ws_ + 4 * NTH) = w1; \
+        if constexpr (WPT > 2) if (WF4 >= 3 * NTH || tid + 2 * NTH < WF4) *reinterpret_cast<float4 *>(ws_ + 8 * NTH) = wq2; \
     }
 
     // ---- X tile: fetch (global -> 3 float4 registers per thread) and commit (SnakeBeta, -> LDS)
@@ -192,15 +195,22 @@ __global__ __launch_bounds__(NTH, (FUSE && TN > 4) ? 2 : 4) void conv_gemm_kerne
     if constexpr (FUSE) {
         // H = snake2(acc + b1), in place.  Register r of tile i is channel i*32 + (r&3) + 8*(r>>2) + 4*h.
         // bias / snake vectors are zero-padded by the loader, so padded rows stay exactly 0.
-        const float *w2p = launder_after(a.w2, acc[0][15]);
+        // staging of the second product's weight tiles: 256*TN float4 per tile through up to six registers
+        constexpr int W2F4 = 256 * TN;
+        static_assert(W2F4 <= 6 * NTH, "W2 staging registers");
+#define W2_PIECE(j_, reg_, base_)                                                                            \
+    if constexpr (W2F4 > (j_) * NTH)                                                                         \
+        if (W2F4 >= ((j_) + 1) * NTH || tid + (j_) * NTH < W2F4)                                             \
+            reg_ = *reinterpret_cast<const float4 *>((base_) + (long)((tid + (j_) * NTH) >> 3) * a.NP + (tid & 7) * 4);
+#define W2_FETCH_FROM(base_) { W2_PIECE(0, xr0, base_) W2_PIECE(1, xr1, base_) W2_PIECE(2, xr2, base_) \
+                               W2_PIECE(3, w0, base_) W2_PIECE(4, w1, base_) W2_PIECE(5, wq2, base_) }
+#define W2_PUT(j_, reg_, dst_)                                                                               \
+    if constexpr (W2F4 > (j_) * NTH)                                                                         \
+        if (W2F4 >= ((j_) + 1) * NTH || tid + (j_) * NTH < W2F4) *reinterpret_cast<float4 *>((dst_) + 4 * (j_) * NTH) = reg_;
         {
-            constexpr int W2F4 = 256 * TN;
-            // tile 0 of the second product's weights: in flight during the activation below
-            if (tid < W2F4) xr0 = *reinterpret_cast<const float4 *>(w2p + (long)(tid >> 3) * a.NP + (tid & 7) * 4);
-            if (W2F4 > NTH && tid + NTH < W2F4)
-                xr1 = *reinterpret_cast<const float4 *>(w2p + (long)((tid + NTH) >> 3) * a.NP + (tid & 7) * 4);
-            if (W2F4 > 2 * NTH && tid + 2 * NTH < W2F4)
-                xr2 = *reinterpret_cast<const float4 *>(w2p + (long)((tid + 2 * NTH) >> 3) * a.NP + (tid & 7) * 4);
+            // tile 0: in flight during the activation below
+            const float *w2p = launder_after(a.w2, acc[0][15]);
+            W2_FETCH_FROM(w2p)
         }
 #pragma unroll
         for (int i = 0; i < TN; i++) {
@@ -226,23 +236,12 @@ __global__ __launch_bounds__(NTH, (FUSE && TN > 4) ? 2 : 4) void conv_gemm_kerne
         // activation prefetch registers: one barrier per output tile, 16*TN MFMAs between barriers.
         float *yu = a.y + (long)unit * a.y_us;
         const int m = m0 + wave * 32 + l31;
-        constexpr int W2F4 = 256 * TN;            // float4 per tile
         constexpr int W2T = 32 * TN * 32;         // floats per tile
-#define W2_FETCH(o_)                                                                                                  \
-    {                                                                                                                 \
-        const float *wq_ = launder_after(a.w2, dep2) + (o_) * 32;                                                     \
-        if (tid < W2F4) xr0 = *reinterpret_cast<const float4 *>(wq_ + (long)(tid >> 3) * a.NP + (tid & 7) * 4);       \
-        if (W2F4 > NTH && tid + NTH < W2F4)                                                                           \
-            xr1 = *reinterpret_cast<const float4 *>(wq_ + (long)((tid + NTH) >> 3) * a.NP + (tid & 7) * 4);           \
-        if (W2F4 > 2 * NTH && tid + 2 * NTH < W2F4)                                                                   \
-            xr2 = *reinterpret_cast<const float4 *>(wq_ + (long)((tid + 2 * NTH) >> 3) * a.NP + (tid & 7) * 4);       \
-    }
-#define W2_COMMIT(buf_)                                                                                               \
-    {                                                                                                                 \
-        float *wd_ = smem + (buf_) * W2T + tid * 4;                                                                   \
-        if (tid < W2F4) *reinterpret_cast<float4 *>(wd_) = xr0;                                                       \
-        if (W2F4 > NTH && tid + NTH < W2F4) *reinterpret_cast<float4 *>(wd_ + 4 * NTH) = xr1;                         \
-        if (W2F4 > 2 * NTH && tid + 2 * NTH < W2F4) *reinterpret_cast<float4 *>(wd_ + 8 * NTH) = xr2;                 \
+#define W2_FETCH(o_) { const float *wq_ = launder_after(a.w2, dep2) + (o_) * 32; W2_FETCH_FROM(wq_) }
+#define W2_COMMIT(buf_)                                                                                      \
+    {                                                                                                        \
+        float *wd_ = smem + (buf_) * W2T + tid * 4;                                                          \
+        W2_PUT(0, xr0, wd_) W2_PUT(1, xr1, wd_) W2_PUT(2, xr2, wd_) W2_PUT(3, w0, wd_) W2_PUT(4, w1, wd_) W2_PUT(5, wq2, wd_) \
     }
         __syncthreads();                          // every wave is done with the main loop's Xs / Ws
         W2_COMMIT(0)
@@ -292,6 +291,9 @@ __global__ __launch_bounds__(NTH, (FUSE && TN > 4) ? 2 : 4) void conv_gemm_kerne
         }
 #undef W2_FETCH
 #undef W2_COMMIT
+#undef W2_PIECE
+#undef W2_FETCH_FROM
+#undef W2_PUT
         return;
     }
 
@@ -333,14 +335,23 @@ __global__ __launch_bounds__(NTH, (FUSE && TN > 4) ? 2 : 4) void conv_gemm_kerne
 #undef W_LOAD
 #undef W_STORE
 
-void detail::conv_gemm_geometry(const ConvGemmArgs &a, int &HL, int &XW) {
+// waves per workgroup of the fp32 kernel for these args: 8 (256 positions), or 4 (128 positions) for the fused
+// residual unit (HIPVOC_FUSE_WAVES, default 4): its long epilogue (activation, second product, residual, store)
+// then overlaps the main loops of the OTHER workgroups of the CU instead of stalling all eight waves at once
+static int conv_gemm_waves(const ConvGemmArgs &a) {
+    static int fw = -1;
+    if (fw < 0) { const char *e = getenv("HIPVOC_FUSE_WAVES"); fw = e && atoi(e) == 8 ? 8 : 4; }
+    return a.w2 ? fw : 8;
+}
+
+void detail::conv_gemm_geometry(const ConvGemmArgs &a, int &HL, int &XW, int bm) {
     int smin = a.shift0, smax = a.shift0;
     int last = a.shift0 + (a.ntaps - 1) * a.shift_step;
     if (last < smin) smin = last;
     if (last > smax) smax = last;
     int hl = smin < 0 ? -smin : 0, hr = smax > 0 ? smax : 0;
     HL = (hl + 3) & ~3;
-    XW = BM + HL + ((hr + 3) & ~3);
+    XW = bm + HL + ((hr + 3) & ~3);
 }
 
 // Tile height actually launched: the packed TN, lowered for small grids (more workgroups), or
@@ -362,24 +373,24 @@ using detail::conv_gemm_launch_tn;
 
 const char *conv_gemm_kernel_name(const ConvGemmArgs &a) {
     if (a.wb) return conv_gemm_bf16_kernel_name(a);
-    static char names[2][8][40];
+    static char names[2][2][8][40];
     int tn = conv_gemm_launch_tn(a);
-    int fuse = a.w2 ? 1 : 0;
-    char *n = names[fuse][tn & 7];
-    if (!n[0]) snprintf(n, 40, "conv_gemm_kernel<%d,%s>", tn, fuse ? "true" : "false");
+    int fuse = a.w2 ? 1 : 0, nw = conv_gemm_waves(a);
+    char *n = names[fuse][nw == 4][tn & 7];
+    if (!n[0]) snprintf(n, 40, "conv_gemm_kernel<%d,%s,%d>", tn, fuse ? "true" : "false", nw);
     return n;
 }
 
 size_t conv_gemm_lds_bytes(const ConvGemmArgs &a) {
     int HL, XW;
-    conv_gemm_geometry(a, HL, XW);
+    conv_gemm_geometry(a, HL, XW, 32 * conv_gemm_waves(a));
     const int tn = conv_gemm_launch_tn(a);
     size_t fl = 2 * (size_t)BK * XW + 2 * (size_t)BK * 32 * tn;
     if (a.w2) fl = fl > 2 * (size_t)32 * tn * 32 ? fl : 2 * (size_t)32 * tn * 32;   // two W2 tiles of the fused second product
     return sizeof(float) * fl;
 }
 
-template <int TN, bool FUSE>
+template <int TN, bool FUSE, int NW>
 static hipError_t conv_gemm_launch_one(const ConvGemmArgs &a, int HL, int XW, int tiles_per_unit, int n_tiles,
                                        long grid, size_t lds, hipStream_t s) {
     static bool done[64] = {};
@@ -387,12 +398,12 @@ static hipError_t conv_gemm_launch_one(const ConvGemmArgs &a, int HL, int XW, in
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 64 && !done[dev]) {   // dynamic LDS above 64 KiB must be enabled per function and device
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_gemm_kernel<TN, FUSE>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_gemm_kernel<TN, FUSE, NW>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         done[dev] = true;
     }
-    hipLaunchKernelGGL((conv_gemm_kernel<TN, FUSE>), dim3((unsigned)grid), dim3(NTH), lds, s, a, HL, XW, tiles_per_unit,
+    hipLaunchKernelGGL((conv_gemm_kernel<TN, FUSE, NW>), dim3((unsigned)grid), dim3(NW * 64), lds, s, a, HL, XW, tiles_per_unit,
                        n_tiles);
     return hipGetLastError();
 }
@@ -407,24 +418,35 @@ hipError_t launch_conv_gemm(const ConvGemmArgs &a_in, hipStream_t s) {
         a.dbg = dbg;
     }
     int HL, XW;
-    conv_gemm_geometry(a, HL, XW);
+    const int nw = conv_gemm_waves(a), bm = 32 * nw;
+    conv_gemm_geometry(a, HL, XW, bm);
     if (a.M <= 0 || a.units <= 0) return hipSuccess;
     // host-side shape checks: what the kernel's vector accesses assume
     if ((a.x_cs & 3) || (a.x_us & 3) || (a.NP % (32 * a.TN)) || a.NP < a.N || a.TN < 1 || a.TN > 4 ||
-        ((uintptr_t)a.x & 15) || ((uintptr_t)a.w & 15) || a.ntaps < 1 || a.S < 1 || BK * (XW / 4) > 3 * NTH)
+        ((uintptr_t)a.x & 15) || ((uintptr_t)a.w & 15) || a.ntaps < 1 || a.S < 1 || BK * (XW / 4) > 3 * 64 * nw)
         return hipErrorInvalidValue;
     const int tn = conv_gemm_launch_tn(a);
     if (a.y2 && (!a.psn_a || !a.psn_ib || a.w2)) return hipErrorInvalidValue;
     if (a.w2 && (a.S != 1 || a.NP != 32 * tn || (a.N + 31) / 32 != tn || tn == 5 || tn > 6 || !a.res || !a.sn2_a ||
                  !a.sn2_ib || !a.bias || !a.bias2 || ((uintptr_t)a.w2 & 15)))
         return hipErrorInvalidValue;
-    int tiles_per_unit = (a.M + BM - 1) / BM;
+    int tiles_per_unit = (a.M + bm - 1) / bm;
     int n_tiles = a.NP / (32 * tn);
     long grid = (long)tiles_per_unit * a.units * n_tiles;
     if (grid > 0x7fffffffL) return hipErrorInvalidValue;
     size_t lds = conv_gemm_lds_bytes(a);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-#define GO(TN_, F_) return conv_gemm_launch_one<TN_, F_>(a, HL, XW, tiles_per_unit, n_tiles, grid, lds, s)
+#define GO(TN_, F_) return conv_gemm_launch_one<TN_, F_, 8>(a, HL, XW, tiles_per_unit, n_tiles, grid, lds, s)
+#define GO4(TN_) return conv_gemm_launch_one<TN_, true, 4>(a, HL, XW, tiles_per_unit, n_tiles, grid, lds, s)
+    if (a.w2 && nw == 4) {
+        switch (tn) {
+            case 1: GO4(1);
+            case 2: GO4(2);
+            case 3: GO4(3);
+            case 4: GO4(4);
+            default: GO4(6);
+        }
+    }
     if (a.w2) {
         switch (tn) {
             case 1: GO(1, true);
@@ -441,6 +463,7 @@ hipError_t launch_conv_gemm(const ConvGemmArgs &a_in, hipStream_t s) {
         default: GO(4, false);
     }
 #undef GO
+#undef GO4
 }
 
 // -------------------------------------------------------------------------------------------------
