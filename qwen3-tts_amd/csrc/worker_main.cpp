@@ -2,10 +2,15 @@
 //
 // Speaks the reference's TCP protocol (u32 BE length + rmp-serde payload, include/hipvoc_wire.h) for the Vocoder
 // role and nothing else: Ping, Init, Vocode (+ the VocodeBatch extension); requests of other roles get the
-// reference's error response and the connection stays up.  One thread per client, requests serialised behind
-// one mutex exactly like the reference's Arc<Mutex<Worker>> (mod.rs:567-577,628-631); the decode itself is
-// libhipvoc (include/hipvoc.h).  The orchestrator (pipeline.rs, the HTTP API) needs no change: point
-// `--vocoder-ip` at this process.
+// reference's error response and the connection stays up.  The orchestrator (pipeline.rs, the HTTP API) needs
+// no change: point `--vocoder-ip` at this process.
+//
+// Serving model.  The reference serialises every request behind one Arc<Mutex<Worker>>
+// (mod.rs:567-577,628-631).  Here each GPU (`--devices 0,1,...`) has one libhipvoc handle, a job queue and one
+// service thread; a client thread enqueues its request on the least-loaded GPU and waits.  A service thread
+// takes EVERYTHING that is queued when it becomes free (up to --max-batch) and decodes it as one batched pass
+// (hipvoc_decode_batch), so concurrent connections are batched across requests without any added latency
+// when the worker is idle.  Results are bit-identical to one request at a time (units are independent).
 #include <arpa/inet.h>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
@@ -13,9 +18,15 @@
 #include <sys/socket.h>
 #include <unistd.h>
 
+#include <poll.h>
+
+#include <atomic>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -24,9 +35,109 @@
 #include "../../include/hipvoc.h"
 #include "../../include/hipvoc_wire.h"
 
-static void *g_voc = nullptr;
-static std::mutex g_mu;
 static const size_t MAX_MSG = 100000000;   // mod.rs:666
+static inline int16_t pcm16(float s);
+
+// One decode job = one utterance ([n,16] i64 codes).  A VocodeBatch request enqueues one job per item.
+struct Job {
+    const int64_t *codes = nullptr;
+    int n_frames = 0;
+    std::vector<int16_t> pcm;
+    int rc = 0;
+    std::string err;
+    bool done = false;
+};
+
+struct Gpu {
+    void *voc = nullptr;
+    int device = 0;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::deque<Job *> q;
+    std::atomic<int> load{0};
+    std::thread th;
+    // stats
+    long batches = 0, jobs = 0, max_batch = 0;
+};
+static std::vector<std::unique_ptr<Gpu>> g_gpus;
+static std::atomic<bool> g_stop{false};
+static int g_max_batch = 256;
+
+static void gpu_service(Gpu *g) {
+    std::vector<Job *> take;
+    for (;;) {
+        take.clear();
+        {
+            std::unique_lock<std::mutex> lk(g->mu);
+            g->cv_work.wait(lk, [&] { return !g->q.empty() || g_stop.load(); });
+            if (g->q.empty()) return;
+            while (!g->q.empty() && (int)take.size() < g_max_batch) { take.push_back(g->q.front()); g->q.pop_front(); }
+            g->batches++; g->jobs += (long)take.size();
+            if ((long)take.size() > g->max_batch) g->max_batch = (long)take.size();
+        }
+        // one batched pass for everything that was waiting
+        size_t B = take.size();
+        std::vector<int64_t> all;
+        std::vector<int32_t> nf(B);
+        std::vector<size_t> off(B + 1, 0), n_out(B, 0);
+        for (size_t j = 0; j < B; j++) {
+            all.insert(all.end(), take[j]->codes, take[j]->codes + (size_t)take[j]->n_frames * 16);
+            nf[j] = take[j]->n_frames;
+            off[j + 1] = off[j] + (size_t)take[j]->n_frames * HIPVOC_SAMPLES_PER_TOKEN;
+        }
+        std::vector<float> wav(off[B] + 1);
+        if (all.empty()) all.push_back(0);
+        int rc = hipvoc_decode_batch(g->voc, all.data(), nf.data(), (int)B, wav.data(), off.data(), n_out.data());
+        std::string err = rc ? hipvoc_last_error(g->voc) : "";
+        if (rc && B > 1) {
+            // a bad request must not fail its batch neighbours: redo them one by one
+            for (size_t j = 0; j < B; j++) {
+                size_t n1 = 0, o1 = 0;
+                int32_t f1 = take[j]->n_frames;
+                std::vector<float> w1((size_t)f1 * HIPVOC_SAMPLES_PER_TOKEN + 1);
+                int64_t zero = 0;
+                const int64_t *cp = f1 ? take[j]->codes : &zero;
+                take[j]->rc = hipvoc_decode_batch(g->voc, cp, &f1, 1, w1.data(), &o1, &n1);
+                if (take[j]->rc) take[j]->err = hipvoc_last_error(g->voc);
+                else { take[j]->pcm.resize(n1); for (size_t k = 0; k < n1; k++) take[j]->pcm[k] = pcm16(w1[k]); }
+            }
+        } else {
+            for (size_t j = 0; j < B; j++) {
+                take[j]->rc = rc;
+                take[j]->err = err;
+                if (!rc) {
+                    take[j]->pcm.resize(n_out[j]);
+                    const float *w = wav.data() + off[j];
+                    for (size_t k = 0; k < n_out[j]; k++) take[j]->pcm[k] = pcm16(w[k]);
+                }
+            }
+        }
+        {
+            std::lock_guard<std::mutex> lk(g->mu);
+            for (Job *j : take) j->done = true;
+        }
+        g->load -= (int)B;
+        g->cv_done.notify_all();
+    }
+}
+
+// enqueue on the least-loaded GPU and wait for all of them
+static void run_jobs(std::vector<Job> &jobs) {
+    if (jobs.empty()) return;
+    static std::atomic<unsigned> rr{0};
+    size_t best = rr++ % g_gpus.size();
+    for (size_t i = 0; i < g_gpus.size(); i++)
+        if (g_gpus[i]->load.load() < g_gpus[best]->load.load()) best = i;
+    Gpu *g = g_gpus[best].get();
+    g->load += (int)jobs.size();
+    {
+        std::lock_guard<std::mutex> lk(g->mu);
+        for (Job &j : jobs) g->q.push_back(&j);
+    }
+    g->cv_work.notify_one();
+    std::unique_lock<std::mutex> lk(g->mu);
+    g->cv_done.wait(lk, [&] { for (Job &j : jobs) if (!j.done) return false; return true; });
+}
 
 static bool read_all(int fd, uint8_t *p, size_t n) {
     while (n) {
@@ -76,18 +187,18 @@ static std::vector<uint8_t> handle(const std::vector<uint8_t> &msg) {
         hipvoc_wire_parse_request(msg.data(), msg.size(), codes.data(), codes.size(), &clen, &nt);
         if (nt > (1u << 24)) return simple(0, "Init", "n_tokens out of range");
         if (clen / 8 < nt * 16) return simple(0, "Init", "codes shorter than n_tokens*16");
-        std::vector<int16_t> pcm((size_t)nt * HIPVOC_SAMPLES_PER_TOKEN + 1);
-        size_t n_samples = 0;
-        int rc;
-        std::string err;
-        {
-            std::lock_guard<std::mutex> lk(g_mu);
-            rc = hipvoc_vocode_pcm16(g_voc, codes.data(), (int)nt, pcm.data(), pcm.size(), &n_samples);
-            if (rc) err = hipvoc_last_error(g_voc);
-        }
-        if (rc) return simple(0, "Init", err.c_str());
-        std::vector<uint8_t> b(hipvoc_wire_encode_vocode(pcm.data(), n_samples, nullptr, 0));
-        hipvoc_wire_encode_vocode(pcm.data(), n_samples, b.data(), b.size());
+        std::vector<int64_t> c64((size_t)nt * 16 + 1);
+        memcpy(c64.data(), codes.data(), (size_t)nt * 16 * 8);          // i64 little-endian == host order (mod.rs:513-516)
+        std::vector<Job> jobs(1);
+        jobs[0].codes = c64.data();
+        jobs[0].n_frames = (int)nt;
+        run_jobs(jobs);
+        if (jobs[0].rc) return simple(0, "Init", jobs[0].err.c_str());
+        std::vector<int16_t> &pcm = jobs[0].pcm;
+        int16_t dummy = 0;
+        const int16_t *pp = pcm.empty() ? &dummy : pcm.data();
+        std::vector<uint8_t> b(hipvoc_wire_encode_vocode(pp, pcm.size(), nullptr, 0));
+        hipvoc_wire_encode_vocode(pp, pcm.size(), b.data(), b.size());
         return b;
     }
     if (kind == HIPVOC_WIRE_VOCODE_BATCH) {
@@ -113,19 +224,18 @@ static std::vector<uint8_t> handle(const std::vector<uint8_t> &msg) {
             nf[j] = (int32_t)nts[j];
             out_off[j + 1] = out_off[j] + nts[j] * HIPVOC_SAMPLES_PER_TOKEN;
         }
-        std::vector<float> wav(out_off[B] + 1);
-        int rc;
-        std::string err;
+        if (all.empty()) all.push_back(0);
+        std::vector<Job> jobs(B);
         {
-            std::lock_guard<std::mutex> lk(g_mu);
-            rc = hipvoc_decode_batch(g_voc, all.data(), nf.data(), (int)B, wav.data(), out_off.data(), n_out.data());
-            if (rc) err = hipvoc_last_error(g_voc);
+            size_t base = 0;
+            for (size_t j = 0; j < B; j++) { jobs[j].codes = all.data() + base; jobs[j].n_frames = nf[j]; base += (size_t)nts[j] * 16; }
         }
-        if (rc) return simple(0, "Init", err.c_str());
+        run_jobs(jobs);
         std::vector<int16_t> pcm;
         std::vector<size_t> so(B + 1, 0);
         for (size_t j = 0; j < B; j++) {
-            for (size_t k = 0; k < n_out[j]; k++) pcm.push_back(pcm16(wav[out_off[j] + k]));
+            if (jobs[j].rc) return simple(0, "Init", jobs[j].err.c_str());
+            pcm.insert(pcm.end(), jobs[j].pcm.begin(), jobs[j].pcm.end());
             so[j + 1] = pcm.size();
         }
         if (pcm.empty()) pcm.push_back(0);
@@ -155,28 +265,45 @@ static void client(int fd) {
     close(fd);
 }
 
+static void on_term(int) { g_stop.store(true); }
+
 int main(int argc, char **argv) {
-    std::string bind_addr = "0.0.0.0:9092", model;
-    int device = 0, dtype = HIPVOC_DTYPE_F32, unit = 64;
+    std::string bind_addr = "0.0.0.0:9092", model, devices = "0";
+    int dtype = HIPVOC_DTYPE_F32, unit = 64;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto next = [&]() -> const char * { return i + 1 < argc ? argv[++i] : ""; };
         if (a == "-b" || a == "--bind") bind_addr = next();
         else if (a == "-m" || a == "--model") model = next();
-        else if (a == "--device") device = atoi(next());
+        else if (a == "--device" || a == "--devices") devices = next();
         else if (a == "--dtype") { std::string d = next(); dtype = d == "bf16" ? HIPVOC_DTYPE_BF16 : HIPVOC_DTYPE_F32; }
         else if (a == "--unit-frames") unit = atoi(next());
+        else if (a == "--max-batch") g_max_batch = atoi(next());
         else if (a == "-r" || a == "--role") { std::string r = next(); if (r != "vocoder") { fprintf(stderr, "hipvoc-worker only serves role 'vocoder'\n"); return 2; } }
-        else { fprintf(stderr, "usage: hipvoc-worker -m <decoder.safetensors> [-b host:port] [--device N] [--dtype f32|bf16] [--unit-frames 64]\n"); return 2; }
+        else { fprintf(stderr, "usage: hipvoc-worker -m <decoder.safetensors> [-b host:port] [--devices 0,1,..] [--dtype f32|bf16] [--unit-frames 64] [--max-batch 256]\n"); return 2; }
     }
     if (model.empty()) { fprintf(stderr, "hipvoc-worker: -m <weights.safetensors> is required\n"); return 2; }
+    if (g_max_batch < 1) g_max_batch = 1;
     size_t colon = bind_addr.rfind(':');
     if (colon == std::string::npos) { fprintf(stderr, "bad bind address\n"); return 2; }
     std::string host = bind_addr.substr(0, colon);
     int port = atoi(bind_addr.c_str() + colon + 1);
 
-    g_voc = hipvoc_load(model.c_str(), device, dtype, unit);
-    if (!g_voc) { fprintf(stderr, "hipvoc-worker: load failed: %s\n", hipvoc_last_error(nullptr)); return 1; }
+    // one handle + service thread per listed device (a device may be listed twice: two handles on one GPU)
+    for (size_t p = 0; p <= devices.size();) {
+        size_t e = devices.find(',', p);
+        if (e == std::string::npos) e = devices.size();
+        if (e > p) {
+            std::unique_ptr<Gpu> g(new Gpu);
+            g->device = atoi(devices.substr(p, e - p).c_str());
+            g->voc = hipvoc_load(model.c_str(), g->device, dtype, unit);
+            if (!g->voc) { fprintf(stderr, "hipvoc-worker: load on device %d failed: %s\n", g->device, hipvoc_last_error(nullptr)); return 1; }
+            g_gpus.push_back(std::move(g));
+        }
+        p = e + 1;
+    }
+    if (g_gpus.empty()) { fprintf(stderr, "hipvoc-worker: no device given\n"); return 2; }
+    for (auto &g : g_gpus) g->th = std::thread(gpu_service, g.get());
 
     int ls = socket(AF_INET, SOCK_STREAM, 0);
     int one = 1;
@@ -188,13 +315,23 @@ int main(int argc, char **argv) {
     if (bind(ls, (sockaddr *)&sa, sizeof sa) != 0 || listen(ls, 64) != 0) { perror("hipvoc-worker: bind/listen"); return 1; }
     socklen_t sl = sizeof sa;
     getsockname(ls, (sockaddr *)&sa, &sl);
-    printf("hipvoc-worker ready, listening on %s:%d (unit %d frames, %s)\n", host.c_str(), (int)ntohs(sa.sin_port), unit,
-           dtype == HIPVOC_DTYPE_BF16 ? "bf16" : "f32");
+    printf("hipvoc-worker ready, listening on %s:%d (unit %d frames, %s, %zu device handle(s))\n", host.c_str(),
+           (int)ntohs(sa.sin_port), unit, dtype == HIPVOC_DTYPE_BF16 ? "bf16" : "f32", g_gpus.size());
     fflush(stdout);
     signal(SIGPIPE, SIG_IGN);
-    for (;;) {
+    signal(SIGTERM, on_term);
+    signal(SIGINT, on_term);
+    while (!g_stop.load()) {
+        pollfd pf{ls, POLLIN, 0};
+        if (poll(&pf, 1, 200) <= 0) continue;
         int fd = accept(ls, nullptr, nullptr);
         if (fd < 0) continue;
         std::thread(client, fd).detach();
     }
+    // drain: service threads exit once their queues are empty
+    for (auto &g : g_gpus) { g->cv_work.notify_all(); g->th.join(); }
+    for (auto &g : g_gpus)
+        printf("hipvoc-worker stats: device %d batches=%ld jobs=%ld max_batch=%ld\n", g->device, g->batches, g->jobs, g->max_batch);
+    fflush(stdout);
+    _exit(0);   // client threads may still sit in recv(); nothing left to flush
 }

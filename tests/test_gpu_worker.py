@@ -83,3 +83,61 @@ def test_worker_rejects_oversize_frame_then_closes(pkg, worker):
     d = wire.WorkerClient("127.0.0.1", worker)     # the worker itself keeps running
     assert d.ping()
     d.close()
+
+
+def test_worker_batches_across_connections_on_two_handles(pkg, synth, worker):
+    """requests of concurrent connections are queued per device handle and decoded as one batched
+    pass; results equal the one-at-a-time results bit for bit (`--devices 0,0` = two handles on this box's GPU)."""
+    import signal
+    import threading
+    wire = pkg.wire
+    cfg = synth.SMALL
+    path = os.path.join(tempfile.gettempdir(), "hipvoc_test_SMALL_0.safetensors")
+    exe = os.path.join(ROOT, "qwen3-tts_amd", "hipvoc-worker")
+    p = subprocess.Popen([exe, "-m", path, "-b", "127.0.0.1:0", "--unit-frames", "4", "--devices", "0,0"],
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    try:
+        line = p.stdout.readline()
+        assert "2 device handle(s)" in line, line
+        port = int(line.split("listening on ")[1].split()[0].rsplit(":", 1)[1])
+        n_clients, n_req = 8, 6
+        seqs = [[synth.make_codes(1 + (3 * c + r) % 11, 500 + 10 * c + r, cfg) for r in range(n_req)] for c in range(n_clients)]
+        ref_client = wire.WorkerClient("127.0.0.1", worker)          # the single-handle worker of this module
+        expect = [[ref_client.vocode(s) for s in row] for row in seqs]
+        ref_client.close()
+        got = [[None] * n_req for _ in range(n_clients)]
+        errs = []
+        gate = threading.Barrier(n_clients)
+
+        def run(c):
+            try:
+                cl = wire.WorkerClient("127.0.0.1", port)
+                for r in range(n_req):
+                    gate.wait(timeout=60)
+                    got[c][r] = cl.vocode(seqs[c][r])
+                cl.close()
+            except Exception as e:  # noqa: BLE001
+                errs.append(repr(e))
+
+        ths = [threading.Thread(target=run, args=(c,)) for c in range(n_clients)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join(timeout=120)
+        assert not errs, errs
+        for c in range(n_clients):
+            for r in range(n_req):
+                assert np.array_equal(got[c][r], expect[c][r]), (c, r)
+        p.send_signal(signal.SIGTERM)
+        out = p.communicate(timeout=30)[0]
+        stats = [ln for ln in out.splitlines() if "stats:" in ln]
+        assert len(stats) == 2, out
+        jobs = sum(int(ln.split("jobs=")[1].split()[0]) for ln in stats)
+        batches = sum(int(ln.split("batches=")[1].split()[0]) for ln in stats)
+        assert jobs == n_clients * n_req
+        assert batches < jobs, f"no request was ever batched with another: {stats}"
+        assert all(int(ln.split("jobs=")[1].split()[0]) > 0 for ln in stats), f"one handle stayed idle: {stats}"
+    finally:
+        if p.poll() is None:
+            p.kill()
+            p.wait()
