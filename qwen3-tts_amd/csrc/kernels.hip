@@ -14,6 +14,14 @@
 
 namespace hipvoc {
 
+// Timing-only ablation switches (HIPVOC_DBG bits; results are WRONG with any of them set) exist only in a
+// build with -DHIPVOC_ABLATE=1 (make ABLATE=1): in the production build the conditions fold away (the runtime
+// tests alone cost ~2 % of conv7).
+#ifndef HIPVOC_ABLATE
+#define HIPVOC_ABLATE 0
+#endif
+#define ABL(bit_) (HIPVOC_ABLATE && (a.dbg & (bit_)))
+
 static constexpr int BM = 256;   // time positions per workgroup (8 waves x 32)
 static constexpr int BK = 16;    // input channels per K stage
 
@@ -153,12 +161,12 @@ __global__ __launch_bounds__(NW * 64, (FUSE && TN > 4) ? 2 : 4) void conv_gemm_k
     X_COMMIT(0, 0)
     W_STORE(0);
     for (int cb = 0; cb < ncb; cb++) {
-        const bool xnext = cb + 1 < ncb && !(a.dbg & 1);
+        const bool xnext = cb + 1 < ncb && !ABL(1);
         if (xnext) X_FETCH(cb + 1)
         for (int tap = 0; tap < a.ntaps; tap++) {
             const int st = cb * a.ntaps + tap;
-            if (st + 1 < nstage && !(a.dbg & 2)) W_LOAD(st + 1);
-            if (!(a.dbg & 4)) __syncthreads();   // Ws[st&1] (and, at tap 0, the committed Xs[cb&1]) are visible
+            if (st + 1 < nstage && !ABL(2)) W_LOAD(st + 1);
+            if (!ABL(4)) __syncthreads();   // Ws[st&1] (and, at tap 0, the committed Xs[cb&1]) are visible
             {
                 const float *ws = Ws + (st & 1) * (BK * BN) + l31;
                 const float *xs = smem + (cb & 1) * xtile + wave * 32 + l31 + HL + a.shift0 + tap * a.shift_step;
@@ -173,7 +181,7 @@ __global__ __launch_bounds__(NW * 64, (FUSE && TN > 4) ? 2 : 4) void conv_gemm_k
                     for (int i = 0; i < TN; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv, acc[i], 0, 0, 0);
                 }
             }
-            if (st + 1 < nstage && !(a.dbg & 2)) W_STORE((st + 1) & 1);
+            if (st + 1 < nstage && !ABL(2)) W_STORE((st + 1) & 1);
         }
         // Xs[(cb+1)&1] was last read during cb-1; every wave has passed a later barrier since
         if (xnext) X_COMMIT(cb + 1, (cb + 1) & 1)
@@ -181,8 +189,8 @@ __global__ __launch_bounds__(NW * 64, (FUSE && TN > 4) ? 2 : 4) void conv_gemm_k
 #undef X_FETCH
 #undef X_COMMIT
 
-    if (a.dbg & 8) {   // timing-only: main loop alone (one never-taken store keeps the MFMAs alive)
-        if (a.dbg & 64) {
+    if (ABL(8)) {   // timing-only: main loop alone (one never-taken store keeps the MFMAs alive)
+        if (ABL(64)) {
             float t = 0.f;
 #pragma unroll
             for (int i = 0; i < TN; i++)
