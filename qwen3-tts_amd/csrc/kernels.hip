@@ -287,15 +287,7 @@ __global__ __launch_bounds__(NW * 64, (FUSE && TN > 4) ? 2 : 4) void conv_gemm_k
             // + b2 + residual x, store this 32-row tile
             const float *b2p = launder_after(a.bias2, acc2[15]);
             const float *pa = launder_after(a.psn_a, acc2[15]), *pb = launder_after(a.psn_ib, acc2[15]);
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                int n = o * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (n >= a.N || m >= a.M) continue;
-                long oo = (long)n * a.y_cs + m;
-                float v = resv[r] + (acc2[r] + b2p[n]);
-                if (pa) v = snake_beta(v, pa[n], pb[n]);
-                yu[oo] = v;
-            }
+            fused_epilogue_tile(a, acc2, resv, o * 32 + 4 * h, m, yu, b2p, pa, pb);
         }
 #undef W2_FETCH
 #undef W2_COMMIT
@@ -315,29 +307,7 @@ __global__ __launch_bounds__(NW * 64, (FUSE && TN > 4) ? 2 : 4) void conv_gemm_k
     float *y2u = y2u0 ? y2u0 + (long)unit * a.y_us : nullptr;
     const int m = m0 + wave * 32 + l31;
 #pragma unroll
-    for (int i = 0; i < TN; i++) {
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            int n = n0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (n >= a.N || m >= a.M) continue;
-            int co = n, ph = 0;
-            if (a.S > 1) { co = n / a.S; ph = n - co * a.S; }
-            float bb = bp ? bp[co] : 0.0f;
-            float sc = scp ? scp[co] : 1.0f;
-            float v = acc[i][r] + bb;
-            if (a.act == ACT_GELU) v = gelu_erf(v);
-            if (scp) v = v * sc;
-            long o = (long)co * a.y_cs + (long)m * a.S + ph;
-            if (ru) v = ru[o] + v;
-            if (a.act == ACT_CLAMP1) v = fminf(fmaxf(v, -1.0f), 1.0f);
-            if (pa) {
-                float sv = snake_beta(v, pa[co], pb[co]);
-                if (y2u) { yu[o] = v; y2u[o] = sv; } else yu[o] = sv;
-            } else {
-                yu[o] = v;
-            }
-        }
-    }
+    for (int i = 0; i < TN; i++) conv_epilogue_tile(a, acc[i], n0 + i * 32 + 4 * h, m, yu, ru, y2u, bp, scp, pa, pb);
 }
 #undef W_LOAD_FROM
 #undef W_LOAD

@@ -16,11 +16,17 @@
 #include "kernels.h"
 
 #include <cstdio>
+#include <cstdlib>
 
 namespace hipvoc {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+#ifndef HIPVOC_ABLATE
+#define HIPVOC_ABLATE 0
+#endif
+#define ABL(bit_) (HIPVOC_ABLATE && (a.dbg & (bit_)))   // timing-only ablations, see kernels.hip
 
 static constexpr int BMB = 256;   // positions per workgroup
 static constexpr int BKB = 32;    // input channels per K block (two MFMA k-steps)
@@ -112,9 +118,14 @@ __global__ __launch_bounds__(NTHB, (TN > 4) ? 2 : 4) void conv_gemm_bf16_kernel(
         if (kq < 4 && pos >= 0 && pos < a.Lin) {
             int c0 = cb * BKB + kq * 8;
             const float *xp = xu + (long)c0 * a.x_cs + pos;
+            if (c0 + 8 <= a.Cin) {      // the common case: eight loads back to back, no per-load branch/wait
 #pragma unroll
-            for (int j = 0; j < 8; j++)
-                if (c0 + j < a.Cin) v[j] = xp[(long)j * a.x_cs];
+                for (int j = 0; j < 8; j++) v[j] = xp[(long)j * a.x_cs];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    if (c0 + j < a.Cin) v[j] = xp[(long)j * a.x_cs];
+            }
         }
         return v;
     };
@@ -139,12 +150,12 @@ __global__ __launch_bounds__(NTHB, (TN > 4) ? 2 : 4) void conv_gemm_bf16_kernel(
     X_COMMIT(0, 0)
     W_STORE(0);
     for (int cb = 0; cb < ncb; cb++) {
-        const bool xnext = cb + 1 < ncb;
+        const bool xnext = cb + 1 < ncb && !ABL(1);
         if (xnext) X_FETCH(cb + 1)
         for (int tap = 0; tap < a.ntaps; tap++) {
             const int st = cb * a.ntaps + tap;
-            if (st + 1 < nstage) W_LOAD(st + 1);
-            __syncthreads();
+            if (st + 1 < nstage && !ABL(2)) W_LOAD(st + 1);
+            if (!ABL(4)) __syncthreads();
             {
                 const bf16x8 *wsb = Ws + (st & 1) * WF + l31;
                 const bf16x8 *xsb = Xs + (cb & 1) * 4 * XW + wave * 32 + l31 + HL + a.shift0 + tap * a.shift_step;
@@ -159,7 +170,7 @@ __global__ __launch_bounds__(NTHB, (TN > 4) ? 2 : 4) void conv_gemm_bf16_kernel(
                     for (int i = 0; i < TN; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv, acc[i], 0, 0, 0);
                 }
             }
-            if (st + 1 < nstage) W_STORE((st + 1) & 1);
+            if (st + 1 < nstage && !ABL(2)) W_STORE((st + 1) & 1);
         }
         if (xnext) X_COMMIT(cb + 1, (cb + 1) & 1)
     }
@@ -168,6 +179,17 @@ __global__ __launch_bounds__(NTHB, (TN > 4) ? 2 : 4) void conv_gemm_bf16_kernel(
 #undef W_LOAD
 #undef W_STORE
 
+    if (ABL(8)) {   // timing-only: main loop alone
+        if (ABL(64)) {
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < TN; i++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) t += acc[i][r];
+            a.y[tid] = t;
+        }
+        return;
+    }
     if constexpr (FUSE) {
         // H = snake2(acc + b1) -> bf16 B operands hb[i][g] (lane's registers 8g..8g+7 of tile i)
         constexpr int W2N = 128 * TN;     // 16-byte elements per W2 tile: [2*TN k-steps][2 lane halves][32 rows]
@@ -234,15 +256,7 @@ __global__ __launch_bounds__(NTHB, (TN > 4) ? 2 : 4) void conv_gemm_bf16_kernel(
             dep2 = acc2[15];
             const float *b2p = launder_after(a.bias2, acc2[15]);
             const float *pa = launder_after(a.psn_a, acc2[15]), *pb = launder_after(a.psn_ib, acc2[15]);
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                int n = o * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (n >= a.N || m >= a.M) continue;
-                long oo = (long)n * a.y_cs + m;
-                float v = resv[r] + (acc2[r] + b2p[n]);
-                if (pa) v = snake_beta(v, pa[n], pb[n]);
-                yu[oo] = v;
-            }
+            fused_epilogue_tile(a, acc2, resv, o * 32 + 4 * h, m, yu, b2p, pa, pb);
         }
         return;
     }
@@ -257,29 +271,7 @@ __global__ __launch_bounds__(NTHB, (TN > 4) ? 2 : 4) void conv_gemm_bf16_kernel(
     float *y2u = y2u0 ? y2u0 + (long)unit * a.y_us : nullptr;
     const int m = m0 + wave * 32 + l31;
 #pragma unroll
-    for (int i = 0; i < TN; i++) {
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            int n = n0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (n >= a.N || m >= a.M) continue;
-            int co = n, ph = 0;
-            if (a.S > 1) { co = n / a.S; ph = n - co * a.S; }
-            float bb = bp ? bp[co] : 0.0f;
-            float sc = scp ? scp[co] : 1.0f;
-            float v = acc[i][r] + bb;
-            if (a.act == ACT_GELU) v = gelu_erf(v);
-            if (scp) v = v * sc;
-            long o = (long)co * a.y_cs + (long)m * a.S + ph;
-            if (ru) v = ru[o] + v;
-            if (a.act == ACT_CLAMP1) v = fminf(fmaxf(v, -1.0f), 1.0f);
-            if (pa) {
-                float sv = snake_beta(v, pa[co], pb[co]);
-                if (y2u) { yu[o] = v; y2u[o] = sv; } else yu[o] = sv;
-            } else {
-                yu[o] = v;
-            }
-        }
-    }
+    for (int i = 0; i < TN; i++) conv_epilogue_tile(a, acc[i], n0 + i * 32 + 4 * h, m, yu, ru, y2u, bp, scp, pa, pb);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -320,7 +312,13 @@ static hipError_t launch_one_bf16(const ConvGemmArgs &a, int HL, int XW, int til
     return hipGetLastError();
 }
 
-hipError_t launch_conv_gemm_bf16(const ConvGemmArgs &a, hipStream_t s) {
+hipError_t launch_conv_gemm_bf16(const ConvGemmArgs &a_in, hipStream_t s) {
+    ConvGemmArgs a = a_in;
+    {
+        static int dbg = -1;
+        if (dbg < 0) { const char *e = getenv("HIPVOC_DBG"); dbg = e ? atoi(e) : 0; }
+        a.dbg = dbg;
+    }
     int HL, XW;
     detail::conv_gemm_geometry(a, HL, XW);
     if (a.M <= 0 || a.units <= 0) return hipSuccess;

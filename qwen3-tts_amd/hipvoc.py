@@ -33,7 +33,8 @@ class HipVocError(RuntimeError):
 
 
 def lib_path() -> str:
-    return os.path.join(_HERE, "libhipvoc.so")
+    # HIPVOC_LIBRARY: another build of the same library (e.g. the timing-ablation build, make ABLATE=1)
+    return os.environ.get("HIPVOC_LIBRARY") or os.path.join(_HERE, "libhipvoc.so")
 
 
 _lib = None
