@@ -8,24 +8,42 @@ namespace hipvoc {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// sin(t)^2 for SnakeBeta.  Quadrant reduction n = rint(t*2/pi), r = t - n*pi/2 by a three-constant
-// Cody-Waite fma chain (exact cancellation under fma; good to |t| ~ 1e5), then the sin or cos
-// minimax polynomial on [-pi/4, pi/4]; the sign is irrelevant because the result is squared.
-// Max error of sin/cos here ~1 ulp, i.e. the same class as libm's sinf the CPU oracle uses.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// sin^2(r)/r^2 - 1 = C1 z + ... + C5 z^5 on z = r^2 in [0, (pi/2)^2] (weighted least squares on Chebyshev nodes,
+// tools/fit_sinsq.py; 9e-9 in exact arithmetic)
+#define SINSQ_C1 -0.3333328366279602f
+#define SINSQ_C2 0.04444241523742676f
+#define SINSQ_C3 -0.003171588061377406f
+#define SINSQ_C4 0.0001389977551298216f
+#define SINSQ_C5 -3.5771574857790256e-06f
+
+// sin(t)^2 for SnakeBeta, on TWO values at a time (every multiply / fma below is a v_pk_*_f32, one instruction
+// for both lanes of the pair; component-wise IEEE, so the scalar form gives bit-identical results).
+// sin^2 has period pi: n = rint(t/pi), r = t - n*pi by a three-constant Cody-Waite fma chain (pi = 3.140625 +
+// 9.67502594e-4 + 1.50995803e-7: the first two have 8 and 11 significant bits, so n*c is exact for |n| < 2^13 and
+// the reduction is good to |t| ~ 2.5e4), then sin^2(r) = z*P(z), z = r^2 in [0, (pi/2)^2], P the degree-5 minimax
+// fit with P(0) = 1 (so sin^2 ~ r^2 keeps its relative accuracy near the zeros).  Max abs error 1.7e-7 against
+// float64 (libm's sinf squared in fp32: 1.2e-7); 7.5 VALU instructions per value instead of the 23 of a
+// quadrant-select sin/cos pair.
+__device__ __forceinline__ f32x2 mk2(float a, float b) { f32x2 v = {a, b}; return v; }
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 sin_sq2(f32x2 t) {
+    f32x2 n = __builtin_elementwise_rint(t * 0.31830988618379067154f);
+    f32x2 r = fma2(n, (f32x2)(-3.140625f), t);
+    r = fma2(n, (f32x2)(-9.675025939941406e-4f), r);
+    r = fma2(n, (f32x2)(-1.5099580252808664e-7f), r);
+    f32x2 z = r * r;
+    f32x2 p = fma2((f32x2)(SINSQ_C5), z, (f32x2)(SINSQ_C4));
+    p = fma2(p, z, (f32x2)(SINSQ_C3));
+    p = fma2(p, z, (f32x2)(SINSQ_C2));
+    p = fma2(p, z, (f32x2)(SINSQ_C1));
+    p = fma2(p, z, (f32x2)(1.0f));
+    return z * p;
+}
 __device__ __forceinline__ float sin_sq(float t) {
-    float n = __builtin_rintf(t * 0.63661977236758134308f);
-    float r = __builtin_fmaf(n, -1.57079625129699707031e+00f, t);
-    r = __builtin_fmaf(n, -7.54978941586159635335e-08f, r);
-    r = __builtin_fmaf(n, -5.39030252995776476554e-15f, r);
-    float r2 = r * r;
-    // sin(r) = r + r^3 * S(r^2),  cos(r) = 1 - r^2/2 + r^4 * C(r^2)
-    float sp = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(2.86567956e-6f, r2, -1.98559923e-4f), r2, 8.33338592e-3f), r2, -1.66666672e-1f);
-    float sv = __builtin_fmaf(r * r2, sp, r);
-    float cp = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(2.44677067e-5f, r2, -1.38877297e-3f), r2, 4.16666567e-2f), r2, -0.5f);
-    float cv = __builtin_fmaf(r2, cp, 1.0f);
-    int q = (int)n;
-    float v = (q & 1) ? cv : sv;
-    return v * v;
+    f32x2 v = sin_sq2((f32x2)(t));
+    return v.x;
 }
 
 // Makes a (wave-uniform) pointer opaque at this point of the program, so loads through it cannot be
@@ -47,7 +65,12 @@ __device__ __forceinline__ T *launder_after(T *p, float dep) {
     return p ? p + z : p;
 }
 
-__device__ __forceinline__ float snake_beta(float x, float ea, float ib) { return x + ib * sin_sq(x * ea); }
+// SnakeBeta: x + 1/(e^beta + 1e-9) * sin(x e^alpha)^2.  The pair form is what the kernels use; both round identically.
+__device__ __forceinline__ f32x2 snake_beta2(f32x2 x, f32x2 ea, f32x2 ib) { return fma2(ib, sin_sq2(x * ea), x); }
+__device__ __forceinline__ float snake_beta(float x, float ea, float ib) {
+    f32x2 v = snake_beta2((f32x2)(x), (f32x2)(ea), (f32x2)(ib));
+    return v.x;
+}
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
@@ -116,12 +139,18 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvGemmArgs &a, const 
             for (int q = 0; q < 8; q++) { ta[q] = pa[co[q]]; tb[q] = pb[co[q]]; }
             if (y2u) {
 #pragma unroll
-                for (int q = 0; q < 8; q++)
-                    if (ok[q]) { yu[o[q]] = v[q]; y2u[o[q]] = snake_beta(v[q], ta[q], tb[q]); }
+                for (int q = 0; q < 8; q += 2) {
+                    f32x2 sv = snake_beta2(mk2(v[q], v[q + 1]), mk2(ta[q], ta[q + 1]), mk2(tb[q], tb[q + 1]));
+                    if (ok[q]) { yu[o[q]] = v[q]; y2u[o[q]] = sv.x; }
+                    if (ok[q + 1]) { yu[o[q + 1]] = v[q + 1]; y2u[o[q + 1]] = sv.y; }
+                }
             } else {
 #pragma unroll
-                for (int q = 0; q < 8; q++)
-                    if (ok[q]) yu[o[q]] = snake_beta(v[q], ta[q], tb[q]);
+                for (int q = 0; q < 8; q += 2) {
+                    f32x2 sv = snake_beta2(mk2(v[q], v[q + 1]), mk2(ta[q], ta[q + 1]), mk2(tb[q], tb[q + 1]));
+                    if (ok[q]) yu[o[q]] = sv.x;
+                    if (ok[q + 1]) yu[o[q + 1]] = sv.y;
+                }
             }
         } else {
 #pragma unroll
@@ -150,7 +179,10 @@ __device__ __forceinline__ void fused_epilogue_tile(const ConvGemmArgs &a, const
 #pragma unroll
             for (int q = 0; q < 8; q++) { ta[q] = pa[n[q]]; tb[q] = pb[n[q]]; }
 #pragma unroll
-            for (int q = 0; q < 8; q++) v[q] = snake_beta(v[q], ta[q], tb[q]);
+            for (int q = 0; q < 8; q += 2) {
+                f32x2 sv = snake_beta2(mk2(v[q], v[q + 1]), mk2(ta[q], ta[q + 1]), mk2(tb[q], tb[q + 1]));
+                v[q] = sv.x; v[q + 1] = sv.y;
+            }
         }
 #pragma unroll
         for (int q = 0; q < 8; q++)

@@ -145,10 +145,9 @@ __global__ __launch_bounds__(NW * 64, (FUSE && TN > 4) ? 2 : 4) void conv_gemm_k
     auto x_commit1 = [&](int buf, int k, int c4, float4 v, float2 sp) {
         if (k >= BK) return;
         if (a.sn_a) {   // SnakeBeta: x + 1/(e^beta+1e-9) * sin(x e^alpha)^2 ; snake(0) == 0 keeps the zero padding
-            v.x = snake_beta(v.x, sp.x, sp.y);
-            v.y = snake_beta(v.y, sp.x, sp.y);
-            v.z = snake_beta(v.z, sp.x, sp.y);
-            v.w = snake_beta(v.w, sp.x, sp.y);
+            f32x2 lo = snake_beta2(mk2(v.x, v.y), (f32x2)(sp.x), (f32x2)(sp.y));
+            f32x2 hi = snake_beta2(mk2(v.z, v.w), (f32x2)(sp.x), (f32x2)(sp.y));
+            v = make_float4(lo.x, lo.y, hi.x, hi.y);
         }
         *reinterpret_cast<float4 *>(smem + buf * xtile + k * XW + c4 * 4) = v;
     };
@@ -227,7 +226,12 @@ __global__ __launch_bounds__(NW * 64, (FUSE && TN > 4) ? 2 : 4) void conv_gemm_k
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 int n = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                acc[i][r] = snake_beta(acc[i][r] + b1p[n], s2a[n], s2b[n]);
+                if (r & 1) {   // registers r-1, r are channels n-1, n: one packed evaluation for the pair
+                    f32x2 hv = snake_beta2(mk2(acc[i][r - 1] + b1p[n - 1], acc[i][r] + b1p[n]), mk2(s2a[n - 1], s2a[n]),
+                                           mk2(s2b[n - 1], s2b[n]));
+                    acc[i][r - 1] = hv.x;
+                    acc[i][r] = hv.y;
+                }
                 // four activations in flight at a time: unbounded, the scheduler interleaves all 16*TN
                 // polynomial chains and their temporaries spill
                 if ((r & 3) == 3) {

@@ -135,10 +135,11 @@ __global__ __launch_bounds__(NTHB, (TN > 4) ? 2 : 4) void conv_gemm_bf16_kernel(
             const float4 *sa = reinterpret_cast<const float4 *>(Sn + cb * BKB + kq * 8);
             const float4 *sb = reinterpret_cast<const float4 *>(Sn + CinP + cb * BKB + kq * 8);
             float4 a0 = sa[0], a1 = sa[1], b0 = sb[0], b1 = sb[1];
-            v[0] = snake_beta(v[0], a0.x, b0.x); v[1] = snake_beta(v[1], a0.y, b0.y);
-            v[2] = snake_beta(v[2], a0.z, b0.z); v[3] = snake_beta(v[3], a0.w, b0.w);
-            v[4] = snake_beta(v[4], a1.x, b1.x); v[5] = snake_beta(v[5], a1.y, b1.y);
-            v[6] = snake_beta(v[6], a1.z, b1.z); v[7] = snake_beta(v[7], a1.w, b1.w);
+            f32x2 p0 = snake_beta2(mk2(v[0], v[1]), mk2(a0.x, a0.y), mk2(b0.x, b0.y));
+            f32x2 p1 = snake_beta2(mk2(v[2], v[3]), mk2(a0.z, a0.w), mk2(b0.z, b0.w));
+            f32x2 p2 = snake_beta2(mk2(v[4], v[5]), mk2(a1.x, a1.y), mk2(b1.x, b1.y));
+            f32x2 p3 = snake_beta2(mk2(v[6], v[7]), mk2(a1.z, a1.w), mk2(b1.z, b1.w));
+            v[0] = p0.x; v[1] = p0.y; v[2] = p1.x; v[3] = p1.y; v[4] = p2.x; v[5] = p2.y; v[6] = p3.x; v[7] = p3.y;
         }
         Xs[buf * 4 * XW + kq * XW + t] = pack8(v);
     };
@@ -204,7 +205,12 @@ __global__ __launch_bounds__(NTHB, (TN > 4) ? 2 : 4) void conv_gemm_bf16_kernel(
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 int n = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                acc[i][r] = snake_beta(acc[i][r] + b1p[n], s2a[n], s2b[n]);
+                if (r & 1) {   // registers r-1, r are channels n-1, n: one packed evaluation for the pair
+                    f32x2 hv = snake_beta2(mk2(acc[i][r - 1] + b1p[n - 1], acc[i][r] + b1p[n]), mk2(s2a[n - 1], s2a[n]),
+                                           mk2(s2b[n - 1], s2b[n]));
+                    acc[i][r - 1] = hv.x;
+                    acc[i][r] = hv.y;
+                }
                 if ((r & 3) == 3) {
                     asm volatile("" : "+v"(acc[i][r - 3]), "+v"(acc[i][r - 2]), "+v"(acc[i][r - 1]), "+v"(acc[i][r]));
                     __builtin_amdgcn_sched_barrier(0);
