@@ -967,7 +967,7 @@ void *hipvoc_load(const char *weights_path, int device_id, int dtype, int unit_f
     c->device = device_id;
     c->unit_frames = unit_frames;
     c->bf16 = dtype == HIPVOC_DTYPE_BF16;
-    if (const char *g = getenv("HIPVOC_GROUP")) c->group = std::max(1, std::min(256, atoi(g)));
+    if (const char *g = getenv("HIPVOC_GROUP")) c->group = std::max(1, std::min(128, atoi(g)));
     if (const char *pf = getenv("HIPVOC_PROFILE")) c->profile = atoi(pf) != 0;
     if (const char *fz = getenv("HIPVOC_FUSE")) c->fuse_res = atoi(fz) != 0;
     if (const char *ps = getenv("HIPVOC_POST_SNAKE")) c->post_snake = atoi(ps) != 0;

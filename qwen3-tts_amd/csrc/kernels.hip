@@ -117,19 +117,30 @@ __global__ __launch_bounds__(NW * 64, (FUSE && TN > 4) ? 2 : 4) void conv_gemm_k
         xk1 = i1 / xw4; xc1 = i1 - xk1 * xw4;
         xk2 = i2 / xw4; xc2 = i2 - xk2 * xw4;
     }
-    auto x_fetch1 = [&](int cb, int k, int c4) -> float4 {
+    // Fetch: ONE unconditional float4 load per piece from a clamped (always valid) address; what must read as
+    // zero (halo before the unit, positions >= Lin, channels >= Cin) is zeroed at commit time.  (With the loads
+    // under per-lane conditions hipcc put an s_waitcnt vmcnt(0) between the pieces: three dependent memory round
+    // trips in front of every channel block's MFMAs instead of a prefetch that overlaps them.)
+    // The lane offset (row inside the block + clamped position) is loop-invariant and 32-bit, the channel block is
+    // wave-uniform: a load is uniform base + lane offset, with no 64-bit address arithmetic in the loop.
+    const int xlim = ((a.Lin + 3) & ~3) - 4;         // last whole float4 of a row (rows are padded to 4)
+    auto lane_off = [&](int k, int c4) -> unsigned {
+        int pos = m0 - HL + c4 * 4;
+        pos = pos < 0 ? 0 : (pos > xlim ? xlim : pos);
+        return (unsigned)(k < BK ? k : 0) * (unsigned)a.x_cs + (unsigned)pos;
+    };
+    const unsigned xo0 = lane_off(xk0, xc0), xo1 = lane_off(xk1, xc1), xo2 = lane_off(xk2, xc2);
+    auto x_fetch1 = [&](int cb, int k, int c4, unsigned off) -> float4 {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        int ci = cb * BK + k;
-        if (k < BK && ci < a.Cin) {
-            const float *xr = xu + (long)ci * a.x_cs;
-            int pos = m0 - HL + c4 * 4;
-            if (pos >= 0 && pos + 4 <= a.Lin) {
-                v = *reinterpret_cast<const float4 *>(xr + pos);
-            } else {
-                if (pos + 0 >= 0 && pos + 0 < a.Lin) v.x = xr[pos + 0];
-                if (pos + 1 >= 0 && pos + 1 < a.Lin) v.y = xr[pos + 1];
-                if (pos + 2 >= 0 && pos + 2 < a.Lin) v.z = xr[pos + 2];
-                if (pos + 3 >= 0 && pos + 3 < a.Lin) v.w = xr[pos + 3];
+        if (k < BK) {     // pieces past the tile (whole waves, mostly) fetch nothing
+            if ((cb + 1) * BK <= a.Cin) {
+                v = *reinterpret_cast<const float4 *>(xu + (long)cb * BK * a.x_cs + off);
+            } else {      // last, partial channel block: rows past Cin read row 0 (discarded at commit)
+                int ci = cb * BK + k;
+                ci = ci < a.Cin ? ci : 0;
+                int pos = m0 - HL + c4 * 4;
+                pos = pos < 0 ? 0 : (pos > xlim ? xlim : pos);
+                v = *reinterpret_cast<const float4 *>(xu + (long)ci * a.x_cs + pos);
             }
         }
         return v;
@@ -139,11 +150,18 @@ __global__ __launch_bounds__(NW * 64, (FUSE && TN > 4) ? 2 : 4) void conv_gemm_k
     float2 xp0 = make_float2(0.f, 0.f), xp1 = xp0, xp2 = xp0;
     auto p_fetch1 = [&](int cb, int k) -> float2 {
         int ci = cb * BK + k;
-        if (a.sn_a && k < BK && ci < a.Cin) return make_float2(a.sn_a[ci], a.sn_ib[ci]);
+        ci = (k < BK && ci < a.Cin) ? ci : 0;        // vectors are zero-padded; a clamped read is discarded
+        if (a.sn_a) return make_float2(a.sn_a[ci], a.sn_ib[ci]);
         return make_float2(0.f, 0.f);
     };
-    auto x_commit1 = [&](int buf, int k, int c4, float4 v, float2 sp) {
+    auto x_commit1 = [&](int cb, int buf, int k, int c4, float4 v, float2 sp) {
         if (k >= BK) return;
+        const int pos = m0 - HL + c4 * 4;
+        const bool ok = cb * BK + k < a.Cin && pos >= 0;     // pos is a multiple of 4: the halo test is per float4
+        v.x = ok && pos + 0 < a.Lin ? v.x : 0.0f;
+        v.y = ok && pos + 1 < a.Lin ? v.y : 0.0f;
+        v.z = ok && pos + 2 < a.Lin ? v.z : 0.0f;
+        v.w = ok && pos + 3 < a.Lin ? v.w : 0.0f;
         if (a.sn_a) {   // SnakeBeta: x + 1/(e^beta+1e-9) * sin(x e^alpha)^2 ; snake(0) == 0 keeps the zero padding
             f32x2 lo = snake_beta2(mk2(v.x, v.y), (f32x2)(sp.x), (f32x2)(sp.y));
             f32x2 hi = snake_beta2(mk2(v.z, v.w), (f32x2)(sp.x), (f32x2)(sp.y));
@@ -151,9 +169,9 @@ __global__ __launch_bounds__(NW * 64, (FUSE && TN > 4) ? 2 : 4) void conv_gemm_k
         }
         *reinterpret_cast<float4 *>(smem + buf * xtile + k * XW + c4 * 4) = v;
     };
-#define X_FETCH(cb_) { xr0 = x_fetch1(cb_, xk0, xc0); xr1 = x_fetch1(cb_, xk1, xc1); xr2 = x_fetch1(cb_, xk2, xc2); \
+#define X_FETCH(cb_) { xr0 = x_fetch1(cb_, xk0, xc0, xo0); xr1 = x_fetch1(cb_, xk1, xc1, xo1); xr2 = x_fetch1(cb_, xk2, xc2, xo2); \
                        xp0 = p_fetch1(cb_, xk0); xp1 = p_fetch1(cb_, xk1); xp2 = p_fetch1(cb_, xk2); }
-#define X_COMMIT(cb_, buf_) { x_commit1(buf_, xk0, xc0, xr0, xp0); x_commit1(buf_, xk1, xc1, xr1, xp1); x_commit1(buf_, xk2, xc2, xr2, xp2); }
+#define X_COMMIT(cb_, buf_) { x_commit1(cb_, buf_, xk0, xc0, xr0, xp0); x_commit1(cb_, buf_, xk1, xc1, xr1, xp1); x_commit1(cb_, buf_, xk2, xc2, xr2, xp2); }
 
     X_FETCH(0)
     W_LOAD(0);
@@ -164,7 +182,9 @@ __global__ __launch_bounds__(NW * 64, (FUSE && TN > 4) ? 2 : 4) void conv_gemm_k
         if (xnext) X_FETCH(cb + 1)
         for (int tap = 0; tap < a.ntaps; tap++) {
             const int st = cb * a.ntaps + tap;
-            if (st + 1 < nstage && !ABL(2)) W_LOAD(st + 1);
+            // unconditional (the last stage re-loads itself into the idle buffer): with the load and the store under
+            // a condition hipcc cannot pair them and waits vmcnt(0) BEFORE every load, draining the activation prefetch
+            if (!ABL(2)) W_LOAD(st + 1 < nstage ? st + 1 : st);
             if (!ABL(4)) __syncthreads();   // Ws[st&1] (and, at tap 0, the committed Xs[cb&1]) are visible
             {
                 const float *ws = Ws + (st & 1) * (BK * BN) + l31;
@@ -180,7 +200,7 @@ __global__ __launch_bounds__(NW * 64, (FUSE && TN > 4) ? 2 : 4) void conv_gemm_k
                     for (int i = 0; i < TN; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv, acc[i], 0, 0, 0);
                 }
             }
-            if (st + 1 < nstage && !ABL(2)) W_STORE((st + 1) & 1);
+            if (!ABL(2)) W_STORE((st + 1) & 1);
         }
         // Xs[(cb+1)&1] was last read during cb-1; every wave has passed a later barrier since
         if (xnext) X_COMMIT(cb + 1, (cb + 1) & 1)

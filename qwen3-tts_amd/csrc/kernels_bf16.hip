@@ -101,39 +101,62 @@ __global__ __launch_bounds__(NTHB, (TN > 4) ? 2 : 4) void conv_gemm_bf16_kernel(
         if constexpr (WPT > 1) if (tid + NTHB < WF) ws_[NTHB] = w1;                             \
     }
 
-    // ---- X staging: (k-group, position) pairs, three rounds of 512
+    // ---- X staging: (k-group, position) pairs p = tid + 512*round, k-group = p / XW, position = p % XW; the LDS
+    // element index of a pair is p itself.  Loop-invariant per-thread state is kept to four registers: one 32-bit
+    // global offset per round (k-group row + clamped position) and one word of packed flags
+    // (per round: k-group [2 bits], pair exists [1], position inside [0, Lin) [1]).
     f32x8 xa, xb, xc;
-    int kqa, kqb, kqc, ta, tb, tc;
+    unsigned offa, offb, offc, xmeta = 0;
     {
-        int p0 = tid, p1 = tid + NTHB, p2 = tid + 2 * NTHB;
-        kqa = p0 / XW; ta = p0 - kqa * XW;
-        kqb = p1 / XW; tb = p1 - kqb * XW;
-        kqc = p2 / XW; tc = p2 - kqc * XW;
+        auto prep = [&](int round, unsigned &off) {
+            int p = tid + round * NTHB;
+            int kq = p / XW, t = p - kq * XW;
+            int pos = m0 - HL + t;
+            bool ok = pos >= 0 && pos < a.Lin;
+            pos = pos < 0 ? 0 : (pos >= a.Lin ? a.Lin - 1 : pos);
+            bool ex = kq < 4;
+            off = (unsigned)((ex ? kq : 0) * 8) * (unsigned)a.x_cs + (unsigned)pos;
+            xmeta |= (unsigned)((ex ? kq : 0) | (ex ? 4 : 0) | (ok ? 8 : 0)) << (4 * round);
+        };
+        prep(0, offa); prep(1, offb); prep(2, offc);
     }
-    auto x_fetch1 = [&](int cb, int kq, int t) -> f32x8 {
-        f32x8 v;
+    // eight unconditional loads from clamped (always valid) addresses; zeroing happens at commit (see kernels.hip).
+    // The channel block and the channel within the group are wave-uniform, so a load is uniform base + lane
+    // offset: no per-element 64-bit address arithmetic in the loop.  (Register pressure matters doubly here: a
+    // spill reload inside the loop counts on vmcnt, which retires in order, so it drains the whole prefetch.)
+    auto x_fetch1 = [&](int cb, int round, unsigned off) -> f32x8 {
+        f32x8 v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const unsigned m = xmeta >> (4 * round);
+        if (m & 4) {      // rounds past the tile (whole waves, mostly) fetch nothing
+            // buffer loads: uniform descriptor (this channel block's base) + lane offset in ONE register + the
+            // channel's row offset in an SGPR: no 64-bit per-row address pairs (16 VGPRs with plain loads).  The
+            // descriptor ends after the last real channel, so rows >= Cin of a partial last block read as 0.
+            const long rows_left = a.Cin - cb * BKB;
+            const long bytes = rows_left * a.x_cs * 4;
+            // (every input is wave-uniform, but the 64-bit address arithmetic runs on the VALU: without the explicit
+            // readfirstlane hipcc wraps each load in a waterfall loop)
+            const unsigned long long ba = reinterpret_cast<unsigned long long>(xu + (long)cb * BKB * a.x_cs);
+            const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)ba), bhi = __builtin_amdgcn_readfirstlane((unsigned)(ba >> 32));
+            const int nrec = __builtin_amdgcn_readfirstlane(bytes < 0x7fffffffL ? (int)bytes : 0x7fffffff);
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                reinterpret_cast<float *>(((unsigned long long)bhi << 32) | blo), 0, nrec, 0x00020000);
+            const unsigned row = __builtin_amdgcn_readfirstlane((unsigned)a.x_cs * 4u);
 #pragma unroll
-        for (int j = 0; j < 8; j++) v[j] = 0.0f;
-        int pos = m0 - HL + t;
-        if (kq < 4 && pos >= 0 && pos < a.Lin) {
-            int c0 = cb * BKB + kq * 8;
-            const float *xp = xu + (long)c0 * a.x_cs + pos;
-            if (c0 + 8 <= a.Cin) {      // the common case: eight loads back to back, no per-load branch/wait
-#pragma unroll
-                for (int j = 0; j < 8; j++) v[j] = xp[(long)j * a.x_cs];
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; j++)
-                    if (c0 + j < a.Cin) v[j] = xp[(long)j * a.x_cs];
-            }
+            for (int j = 0; j < 8; j++)
+                v[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off * 4u, (unsigned)j * row, 0));
         }
         return v;
     };
-    auto x_commit1 = [&](int cb, int buf, int kq, int t, f32x8 v) {
-        if (kq >= 4) return;
+    auto x_commit1 = [&](int cb, int buf, int round, f32x8 v) {
+        const unsigned m = xmeta >> (4 * round);
+        if (!(m & 4)) return;
+        const int kq = m & 3, c0 = cb * BKB + kq * 8;
+        const bool ok = (m & 8) != 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = ok ? v[j] : 0.0f;     // (channels >= Cin already read as 0)
         if (a.sn_a) {
-            const float4 *sa = reinterpret_cast<const float4 *>(Sn + cb * BKB + kq * 8);
-            const float4 *sb = reinterpret_cast<const float4 *>(Sn + CinP + cb * BKB + kq * 8);
+            const float4 *sa = reinterpret_cast<const float4 *>(Sn + c0);
+            const float4 *sb = reinterpret_cast<const float4 *>(Sn + CinP + c0);
             float4 a0 = sa[0], a1 = sa[1], b0 = sb[0], b1 = sb[1];
             f32x2 p0 = snake_beta2(mk2(v[0], v[1]), mk2(a0.x, a0.y), mk2(b0.x, b0.y));
             f32x2 p1 = snake_beta2(mk2(v[2], v[3]), mk2(a0.z, a0.w), mk2(b0.z, b0.w));
@@ -141,10 +164,10 @@ __global__ __launch_bounds__(NTHB, (TN > 4) ? 2 : 4) void conv_gemm_bf16_kernel(
             f32x2 p3 = snake_beta2(mk2(v[6], v[7]), mk2(a1.z, a1.w), mk2(b1.z, b1.w));
             v[0] = p0.x; v[1] = p0.y; v[2] = p1.x; v[3] = p1.y; v[4] = p2.x; v[5] = p2.y; v[6] = p3.x; v[7] = p3.y;
         }
-        Xs[buf * 4 * XW + kq * XW + t] = pack8(v);
+        Xs[buf * 4 * XW + tid + round * NTHB] = pack8(v);
     };
-#define X_FETCH(cb_) { xa = x_fetch1(cb_, kqa, ta); xb = x_fetch1(cb_, kqb, tb); xc = x_fetch1(cb_, kqc, tc); }
-#define X_COMMIT(cb_, buf_) { x_commit1(cb_, buf_, kqa, ta, xa); x_commit1(cb_, buf_, kqb, tb, xb); x_commit1(cb_, buf_, kqc, tc, xc); }
+#define X_FETCH(cb_) { xa = x_fetch1(cb_, 0, offa); xb = x_fetch1(cb_, 1, offb); xc = x_fetch1(cb_, 2, offc); }
+#define X_COMMIT(cb_, buf_) { x_commit1(cb_, buf_, 0, xa); x_commit1(cb_, buf_, 1, xb); x_commit1(cb_, buf_, 2, xc); }
 
     X_FETCH(0)
     W_LOAD(0);
@@ -155,7 +178,9 @@ __global__ __launch_bounds__(NTHB, (TN > 4) ? 2 : 4) void conv_gemm_bf16_kernel(
         if (xnext) X_FETCH(cb + 1)
         for (int tap = 0; tap < a.ntaps; tap++) {
             const int st = cb * a.ntaps + tap;
-            if (st + 1 < nstage && !ABL(2)) W_LOAD(st + 1);
+            // unconditional (the last stage re-loads itself into the idle buffer): with the load and the store under
+            // a condition hipcc cannot pair them and waits vmcnt(0) BEFORE every load, draining the activation prefetch
+            if (!ABL(2)) W_LOAD(st + 1 < nstage ? st + 1 : st);
             if (!ABL(4)) __syncthreads();
             {
                 const bf16x8 *wsb = Ws + (st & 1) * WF + l31;
@@ -171,7 +196,7 @@ __global__ __launch_bounds__(NTHB, (TN > 4) ? 2 : 4) void conv_gemm_bf16_kernel(
                     for (int i = 0; i < TN; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv, acc[i], 0, 0, 0);
                 }
             }
-            if (st + 1 < nstage && !ABL(2)) W_STORE((st + 1) & 1);
+            if (!ABL(2)) W_STORE((st + 1) & 1);
         }
         if (xnext) X_COMMIT(cb + 1, (cb + 1) & 1)
     }
@@ -330,7 +355,8 @@ hipError_t launch_conv_gemm_bf16(const ConvGemmArgs &a_in, hipStream_t s) {
     if (a.M <= 0 || a.units <= 0) return hipSuccess;
     // host-side shape checks: what the kernel's staging loops and vector accesses assume
     if (!a.wb || (a.NP % (32 * a.TN)) || a.NP < a.N || a.TN < 1 || a.TN > 4 || ((uintptr_t)a.wb & 15) || a.ntaps < 1 ||
-        a.S < 1 || 4 * XW > 3 * NTHB)
+        a.S < 1 || 4 * XW > 3 * NTHB ||
+        (long)a.x_cs * 4 * (BKB + 1) >= 0x7fffffffL)   // 32-bit byte offsets of the buffer loads (a channel block + a row)
         return hipErrorInvalidValue;
     const int tn = detail::conv_gemm_launch_tn(a);
     if (a.y2 && (!a.psn_a || !a.psn_ib || a.wb2)) return hipErrorInvalidValue;
