@@ -75,57 +75,77 @@ __device__ __forceinline__ float snake_beta(float x, float ea, float ib) {
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 
+// Per-row parameter table in LDS, filled once at kernel start and read by the epilogues (and, in the fused
+// residual unit, by the in-register activation).  Reading bias / scale / SnakeBeta parameters from global memory
+// inside the epilogue costs a dependent L2 round trip per batch -- dozens per workgroup -- while the table costs
+// one load per row, issued before the main loop and long complete when it is needed; indexing it by tile ROW also
+// removes the n / S division of transposed convs from the epilogue.
+//   unfused: [4][BN]  bias | rscale | psn_a | psn_ib      (entries of absent vectors are never read)
+//   fused:   [6][BN]  bias1 | sn2_a | sn2_ib | bias2 | psn_a | psn_ib
+// All source vectors are zero-padded by the loader, so padded rows read zeros.
+template <int BN, bool FUSE>
+__device__ __forceinline__ void fill_param_table(const ConvGemmArgs &a, float *Pm, int n0, int tid, int nthreads) {
+    for (int row = tid; row < BN; row += nthreads) {
+        const int n = n0 + row;
+        const int co = a.S > 1 ? n / a.S : n;
+        if constexpr (FUSE) {
+            Pm[0 * BN + row] = a.bias[co];
+            Pm[1 * BN + row] = a.sn2_a[co];
+            Pm[2 * BN + row] = a.sn2_ib[co];
+            Pm[3 * BN + row] = a.bias2[co];
+            if (a.psn_a) { Pm[4 * BN + row] = a.psn_a[co]; Pm[5 * BN + row] = a.psn_ib[co]; }
+        } else {
+            if (a.bias) Pm[0 * BN + row] = a.bias[co];
+            if (a.rscale) Pm[1 * BN + row] = a.rscale[co];
+            if (a.psn_a) { Pm[2 * BN + row] = a.psn_a[co]; Pm[3 * BN + row] = a.psn_ib[co]; }
+        }
+    }
+}
+
 // Epilogue of one 32-row accumulator tile (fp32): bias, GELU, per-channel scale, residual, clamp, optional
-// SnakeBeta (to y, or to y2 beside the raw y), store.  Register r of the tile is row nbase + (r&3) + 8*(r>>2)
-// (nbase already holds the lane half's +4h), column m.
-// Every per-channel vector and the residual are fetched as BATCHES of eight unconditional loads under
-// wave-uniform `if`s: a per-element `ptr ? ptr[i] : 0` makes hipcc branch around each load and wait for it,
-// i.e. 3-4 dependent memory round trips for each of the 16*TN elements of a lane (measured: 5 % of the fp32
-// conv7 kernels, 35 % of the 1x1 convs, 38 % of a bf16-mode pass).  Vectors are zero-padded by the loader, so
-// padded rows index them safely; an out-of-range element reads residual offset 0 and is never stored.
-__device__ __forceinline__ void conv_epilogue_tile(const ConvGemmArgs &a, const f32x16 &acc, int nbase, int m, float *yu,
-                                                   const float *ru, float *y2u, const float *bp, const float *scp,
-                                                   const float *pa, const float *pb) {
+// SnakeBeta (to y, or to y2 beside the raw y), store.  Register r of the tile is tile row rbase + (r&3) + 8*(r>>2)
+// (rbase = 32*i + 4h), output row n0 + that, column m.  Parameters come from the LDS table; the residual is
+// fetched as one batch of eight unconditional loads under a wave-uniform `if` (a per-element `ptr ? ptr[i] : 0`
+// makes hipcc branch around each load and wait for it; measured: 5 % of the fp32 conv7 kernels, 35 % of the 1x1
+// convs, 38 % of a bf16-mode pass).  An out-of-range element reads residual offset 0 and is never stored.
+template <int BN>
+__device__ __forceinline__ void conv_epilogue_tile(const ConvGemmArgs &a, const f32x16 &acc, const float *Pm, int n0, int rbase,
+                                                   int m, float *yu, const float *ru, float *y2u) {
 #pragma unroll
     for (int half = 0; half < 2; half++) {
-        int co[8];
         long o[8];
         bool ok[8];
+        int row[8];
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             const int r = half * 8 + q;
-            const int n = nbase + (r & 3) + 8 * (r >> 2);
+            row[q] = rbase + (r & 3) + 8 * (r >> 2);
+            const int n = n0 + row[q];
             ok[q] = n < a.N && m < a.M;
             int c = n, ph = 0;
             if (a.S > 1) { c = n / a.S; ph = n - c * a.S; }
-            co[q] = c;
             o[q] = (long)c * a.y_cs + (long)m * a.S + ph;
         }
-        float v[8];
+        float v[8], t[8];
 #pragma unroll
         for (int q = 0; q < 8; q++) v[q] = acc[half * 8 + q];
-        if (bp) {
-            float t[8];
+        if (ru) {
 #pragma unroll
-            for (int q = 0; q < 8; q++) t[q] = bp[co[q]];
+            for (int q = 0; q < 8; q++) t[q] = ru[ok[q] ? o[q] : 0];
+        }
+        if (a.bias) {
 #pragma unroll
-            for (int q = 0; q < 8; q++) v[q] += t[q];
+            for (int q = 0; q < 8; q++) v[q] += Pm[0 * BN + row[q]];
         }
         if (a.act == ACT_GELU) {
 #pragma unroll
             for (int q = 0; q < 8; q++) v[q] = gelu_erf(v[q]);
         }
-        if (scp) {
-            float t[8];
+        if (a.rscale) {
 #pragma unroll
-            for (int q = 0; q < 8; q++) t[q] = scp[co[q]];
-#pragma unroll
-            for (int q = 0; q < 8; q++) v[q] *= t[q];
+            for (int q = 0; q < 8; q++) v[q] *= Pm[1 * BN + row[q]];
         }
         if (ru) {
-            float t[8];
-#pragma unroll
-            for (int q = 0; q < 8; q++) t[q] = ru[ok[q] ? o[q] : 0];
 #pragma unroll
             for (int q = 0; q < 8; q++) v[q] = t[q] + v[q];
         }
@@ -133,21 +153,20 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvGemmArgs &a, const 
 #pragma unroll
             for (int q = 0; q < 8; q++) v[q] = fminf(fmaxf(v[q], -1.0f), 1.0f);
         }
-        if (pa) {
-            float ta[8], tb[8];
-#pragma unroll
-            for (int q = 0; q < 8; q++) { ta[q] = pa[co[q]]; tb[q] = pb[co[q]]; }
+        if (a.psn_a) {
             if (y2u) {
 #pragma unroll
                 for (int q = 0; q < 8; q += 2) {
-                    f32x2 sv = snake_beta2(mk2(v[q], v[q + 1]), mk2(ta[q], ta[q + 1]), mk2(tb[q], tb[q + 1]));
+                    f32x2 sv = snake_beta2(mk2(v[q], v[q + 1]), mk2(Pm[2 * BN + row[q]], Pm[2 * BN + row[q + 1]]),
+                                           mk2(Pm[3 * BN + row[q]], Pm[3 * BN + row[q + 1]]));
                     if (ok[q]) { yu[o[q]] = v[q]; y2u[o[q]] = sv.x; }
                     if (ok[q + 1]) { yu[o[q + 1]] = v[q + 1]; y2u[o[q + 1]] = sv.y; }
                 }
             } else {
 #pragma unroll
                 for (int q = 0; q < 8; q += 2) {
-                    f32x2 sv = snake_beta2(mk2(v[q], v[q + 1]), mk2(ta[q], ta[q + 1]), mk2(tb[q], tb[q + 1]));
+                    f32x2 sv = snake_beta2(mk2(v[q], v[q + 1]), mk2(Pm[2 * BN + row[q]], Pm[2 * BN + row[q + 1]]),
+                                           mk2(Pm[3 * BN + row[q]], Pm[3 * BN + row[q + 1]]));
                     if (ok[q]) yu[o[q]] = sv.x;
                     if (ok[q + 1]) yu[o[q + 1]] = sv.y;
                 }
@@ -161,26 +180,23 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvGemmArgs &a, const 
 }
 
 // Epilogue of one output tile of the fused residual unit: y = res + (acc2 + b2) [then SnakeBeta]; resv holds the
-// residual prefetched before the second product.
-__device__ __forceinline__ void fused_epilogue_tile(const ConvGemmArgs &a, const f32x16 &acc2, const float *resv, int nbase,
-                                                    int m, float *yu, const float *b2p, const float *pa, const float *pb) {
+// residual prefetched before the second product; parameters from the LDS table (rows rbase + ...).
+template <int BN>
+__device__ __forceinline__ void fused_epilogue_tile(const ConvGemmArgs &a, const f32x16 &acc2, const float *resv, const float *Pm,
+                                                    int rbase, int m, float *yu) {
 #pragma unroll
     for (int half = 0; half < 2; half++) {
         int n[8];
-        float v[8], t[8];
+        float v[8];
 #pragma unroll
-        for (int q = 0; q < 8; q++) { const int r = half * 8 + q; n[q] = nbase + (r & 3) + 8 * (r >> 2); }
+        for (int q = 0; q < 8; q++) { const int r = half * 8 + q; n[q] = rbase + (r & 3) + 8 * (r >> 2); }
 #pragma unroll
-        for (int q = 0; q < 8; q++) t[q] = b2p[n[q]];
-#pragma unroll
-        for (int q = 0; q < 8; q++) v[q] = resv[half * 8 + q] + (acc2[half * 8 + q] + t[q]);
-        if (pa) {
-            float ta[8], tb[8];
-#pragma unroll
-            for (int q = 0; q < 8; q++) { ta[q] = pa[n[q]]; tb[q] = pb[n[q]]; }
+        for (int q = 0; q < 8; q++) v[q] = resv[half * 8 + q] + (acc2[half * 8 + q] + Pm[3 * BN + n[q]]);
+        if (a.psn_a) {
 #pragma unroll
             for (int q = 0; q < 8; q += 2) {
-                f32x2 sv = snake_beta2(mk2(v[q], v[q + 1]), mk2(ta[q], ta[q + 1]), mk2(tb[q], tb[q + 1]));
+                f32x2 sv = snake_beta2(mk2(v[q], v[q + 1]), mk2(Pm[4 * BN + n[q]], Pm[4 * BN + n[q + 1]]),
+                                       mk2(Pm[5 * BN + n[q]], Pm[5 * BN + n[q + 1]]));
                 v[q] = sv.x; v[q + 1] = sv.y;
             }
         }

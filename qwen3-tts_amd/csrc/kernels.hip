@@ -52,9 +52,12 @@ __global__ __launch_bounds__(NW * 64, (FUSE && TN > 4) ? 2 : 4) void conv_gemm_k
     constexpr int WF4 = 4 * BN;                      // float4 per W tile [BK][BN]
     constexpr int WPT = (WF4 + NTH - 1) / NTH;       // float4 per thread
     static_assert(WPT <= 3, "W staging registers");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    extern __shared__ __attribute__((aligned(16))) float smem_all[];
+    constexpr int PMF = (FUSE ? 6 : 4) * BN;         // per-row parameter table (device_common.h) at the start of LDS
+    float *Pm = smem_all;
+    float *smem = smem_all + PMF;                    // Xs[2][BK][XW], then Ws[2][BK][BN]
     const int xtile = BK * XW;
-    float *Ws = smem + 2 * xtile;                    // [2][BK][BN] after Xs[2][BK][XW]
+    float *Ws = smem + 2 * xtile;
 
     // XCD-aware remap (bijective): blocks that share an activation tile (same position tile,
     // different row tiles) get consecutive ids on one XCD, so the tile is fetched into one L2.
@@ -75,6 +78,8 @@ __global__ __launch_bounds__(NW * 64, (FUSE && TN > 4) ? 2 : 4) void conv_gemm_k
     const int CinP = ((a.Cin + 31) / 32) * 32;       // row count per tap of the packed weight tensor
     const int nstage = ncb * a.ntaps;
     const int xw4 = XW >> 2;
+
+    fill_param_table<BN, FUSE>(a, Pm, n0, tid, NTH);     // read after the main loop (barriers in between)
 
     f32x16 acc[TN];
 #pragma unroll
@@ -241,19 +246,15 @@ __global__ __launch_bounds__(NW * 64, (FUSE && TN > 4) ? 2 : 4) void conv_gemm_k
         }
 #pragma unroll
         for (int i = 0; i < TN; i++) {
-            const float *b1p = launder_after(a.bias, acc[i][15]), *s2a = launder_after(a.sn2_a, acc[i][15]),
-                        *s2b = launder_after(a.sn2_ib, acc[i][15]);
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 int n = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (r & 1) {   // registers r-1, r are channels n-1, n: one packed evaluation for the pair
-                    f32x2 hv = snake_beta2(mk2(acc[i][r - 1] + b1p[n - 1], acc[i][r] + b1p[n]), mk2(s2a[n - 1], s2a[n]),
-                                           mk2(s2b[n - 1], s2b[n]));
+                    f32x2 hv = snake_beta2(mk2(acc[i][r - 1] + Pm[n - 1], acc[i][r] + Pm[n]), mk2(Pm[BN + n - 1], Pm[BN + n]),
+                                           mk2(Pm[2 * BN + n - 1], Pm[2 * BN + n]));
                     acc[i][r - 1] = hv.x;
                     acc[i][r] = hv.y;
                 }
-                // four activations in flight at a time: unbounded, the scheduler interleaves all 16*TN
-                // polynomial chains and their temporaries spill
                 if ((r & 3) == 3) {
                     // ... and the results are pinned here: without it LLVM sinks the polynomial tails to their first
                     // use in the second product, where all 16*TN chains become live at once
@@ -309,9 +310,7 @@ __global__ __launch_bounds__(NW * 64, (FUSE && TN > 4) ? 2 : 4) void conv_gemm_k
             if (o + 1 < TN) W2_COMMIT((o + 1) & 1)
             dep2 = acc2[15];
             // + b2 + residual x, store this 32-row tile
-            const float *b2p = launder_after(a.bias2, acc2[15]);
-            const float *pa = launder_after(a.psn_a, acc2[15]), *pb = launder_after(a.psn_ib, acc2[15]);
-            fused_epilogue_tile(a, acc2, resv, o * 32 + 4 * h, m, yu, b2p, pa, pb);
+            fused_epilogue_tile<BN>(a, acc2, resv, Pm, o * 32 + 4 * h, m, yu);
         }
 #undef W2_FETCH
 #undef W2_COMMIT
@@ -325,13 +324,11 @@ __global__ __launch_bounds__(NW * 64, (FUSE && TN > 4) ? 2 : 4) void conv_gemm_k
     float *yu = a.y + (long)unit * a.y_us;
     const float *ru0 = launder_after(a.res, acc[TN - 1][15]);
     const float *ru = ru0 ? ru0 + (long)unit * a.y_us : nullptr;
-    const float *bp = launder_after(a.bias, acc[TN - 1][15]), *scp = launder_after(a.rscale, acc[TN - 1][15]);
-    const float *pa = launder_after(a.psn_a, acc[TN - 1][15]), *pb = launder_after(a.psn_ib, acc[TN - 1][15]);
     float *y2u0 = launder_after(a.y2, acc[TN - 1][15]);
     float *y2u = y2u0 ? y2u0 + (long)unit * a.y_us : nullptr;
     const int m = m0 + wave * 32 + l31;
 #pragma unroll
-    for (int i = 0; i < TN; i++) conv_epilogue_tile(a, acc[i], n0 + i * 32 + 4 * h, m, yu, ru, y2u, bp, scp, pa, pb);
+    for (int i = 0; i < TN; i++) conv_epilogue_tile<BN>(a, acc[i], Pm, n0, i * 32 + 4 * h, m, yu, ru, y2u);
 }
 #undef W_LOAD_FROM
 #undef W_LOAD
@@ -389,6 +386,7 @@ size_t conv_gemm_lds_bytes(const ConvGemmArgs &a) {
     const int tn = conv_gemm_launch_tn(a);
     size_t fl = 2 * (size_t)BK * XW + 2 * (size_t)BK * 32 * tn;
     if (a.w2) fl = fl > 2 * (size_t)32 * tn * 32 ? fl : 2 * (size_t)32 * tn * 32;   // two W2 tiles of the fused second product
+    fl += (size_t)(a.w2 ? 6 : 4) * 32 * tn;                                          // per-row parameter table
     return sizeof(float) * fl;
 }
 

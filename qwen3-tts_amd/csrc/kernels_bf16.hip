@@ -46,7 +46,10 @@ __global__ __launch_bounds__(NTHB, (TN > 4) ? 2 : 4) void conv_gemm_bf16_kernel(
     constexpr int WF = 4 * BN;                        // 16-byte elements per W tile [4 k-groups][BN rows]
     constexpr int WPT = (WF + NTHB - 1) / NTHB;       // per thread: 1 (TN <= 4) or 2 (TN = 6)
     static_assert(WPT <= 2, "W staging registers");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    constexpr int PMF = (FUSE ? 6 : 4) * BN;                     // per-row parameter table (device_common.h), first in LDS
+    float *Pm = reinterpret_cast<float *>(smem_all);
+    unsigned char *smem_raw = smem_all + PMF * sizeof(float);
     bf16x8 *Xs = reinterpret_cast<bf16x8 *>(smem_raw);          // [2][4][XW]
     bf16x8 *Ws = Xs + 2 * 4 * XW;                                // [2][4][BN]
     float *Sn = reinterpret_cast<float *>(Ws + 2 * WF);          // [2][CinP]: exp(alpha) | 1/(exp(beta)+1e-9)
@@ -68,6 +71,7 @@ __global__ __launch_bounds__(NTHB, (TN > 4) ? 2 : 4) void conv_gemm_bf16_kernel(
     const int CinP = ncb * BKB;
     const int nstage = ncb * a.ntaps;
 
+    fill_param_table<BN, FUSE>(a, Pm, n0, tid, NTHB);           // read after the main loop (barriers in between)
     if (a.sn_a) {
         for (int i = tid; i < CinP; i += NTHB) {
             Sn[i] = i < a.Cin ? a.sn_a[i] : 0.0f;
@@ -225,14 +229,12 @@ __global__ __launch_bounds__(NTHB, (TN > 4) ? 2 : 4) void conv_gemm_bf16_kernel(
         bf16x8 hb[TN][2];
 #pragma unroll
         for (int i = 0; i < TN; i++) {
-            const float *b1p = launder_after(a.bias, acc[i][15]), *s2a = launder_after(a.sn2_a, acc[i][15]),
-                        *s2b = launder_after(a.sn2_ib, acc[i][15]);
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 int n = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (r & 1) {   // registers r-1, r are channels n-1, n: one packed evaluation for the pair
-                    f32x2 hv = snake_beta2(mk2(acc[i][r - 1] + b1p[n - 1], acc[i][r] + b1p[n]), mk2(s2a[n - 1], s2a[n]),
-                                           mk2(s2b[n - 1], s2b[n]));
+                    f32x2 hv = snake_beta2(mk2(acc[i][r - 1] + Pm[n - 1], acc[i][r] + Pm[n]), mk2(Pm[BN + n - 1], Pm[BN + n]),
+                                           mk2(Pm[2 * BN + n - 1], Pm[2 * BN + n]));
                     acc[i][r - 1] = hv.x;
                     acc[i][r] = hv.y;
                 }
@@ -285,9 +287,7 @@ __global__ __launch_bounds__(NTHB, (TN > 4) ? 2 : 4) void conv_gemm_bf16_kernel(
                 if constexpr (W2N > NTHB) if (tid + NTHB < W2N) wd_[tid + NTHB] = w1;
             }
             dep2 = acc2[15];
-            const float *b2p = launder_after(a.bias2, acc2[15]);
-            const float *pa = launder_after(a.psn_a, acc2[15]), *pb = launder_after(a.psn_ib, acc2[15]);
-            fused_epilogue_tile(a, acc2, resv, o * 32 + 4 * h, m, yu, b2p, pa, pb);
+            fused_epilogue_tile<BN>(a, acc2, resv, Pm, o * 32 + 4 * h, m, yu);
         }
         return;
     }
@@ -296,13 +296,11 @@ __global__ __launch_bounds__(NTHB, (TN > 4) ? 2 : 4) void conv_gemm_bf16_kernel(
     float *yu = a.y + (long)unit * a.y_us;
     const float *ru0 = launder_after(a.res, acc[TN - 1][15]);
     const float *ru = ru0 ? ru0 + (long)unit * a.y_us : nullptr;
-    const float *bp = launder_after(a.bias, acc[TN - 1][15]), *scp = launder_after(a.rscale, acc[TN - 1][15]);
-    const float *pa = launder_after(a.psn_a, acc[TN - 1][15]), *pb = launder_after(a.psn_ib, acc[TN - 1][15]);
     float *y2u0 = launder_after(a.y2, acc[TN - 1][15]);
     float *y2u = y2u0 ? y2u0 + (long)unit * a.y_us : nullptr;
     const int m = m0 + wave * 32 + l31;
 #pragma unroll
-    for (int i = 0; i < TN; i++) conv_epilogue_tile(a, acc[i], n0 + i * 32 + 4 * h, m, yu, ru, y2u, bp, scp, pa, pb);
+    for (int i = 0; i < TN; i++) conv_epilogue_tile<BN>(a, acc[i], Pm, n0, i * 32 + 4 * h, m, yu, ru, y2u);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -313,6 +311,7 @@ size_t conv_gemm_bf16_lds_bytes(const ConvGemmArgs &a) {
     const int CinP = (a.Cin + BKB - 1) / BKB * BKB;
     size_t b = 16 * (2 * 4 * (size_t)XW + 2 * 4 * (size_t)32 * tn) + (a.sn_a ? 2 * sizeof(float) * CinP : 0);
     if (a.wb2) b = b > 2 * 16 * (size_t)128 * tn ? b : 2 * 16 * (size_t)128 * tn;
+    b += sizeof(float) * (a.wb2 ? 6 : 4) * 32 * tn;     // per-row parameter table
     return b;
 }
 
