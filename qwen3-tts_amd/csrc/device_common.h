@@ -108,9 +108,17 @@ __device__ __forceinline__ void fill_param_table(const ConvGemmArgs &a, float *P
 // fetched as one batch of eight unconditional loads under a wave-uniform `if` (a per-element `ptr ? ptr[i] : 0`
 // makes hipcc branch around each load and wait for it; measured: 5 % of the fp32 conv7 kernels, 35 % of the 1x1
 // convs, 38 % of a bf16-mode pass).  An out-of-range element reads residual offset 0 and is never stored.
+__device__ __forceinline__ unsigned short bf16_bits(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+__device__ __forceinline__ uint2 pack4_bf16(float a, float b, float c, float d) {
+    return make_uint2((unsigned)bf16_bits(a) | ((unsigned)bf16_bits(b) << 16), (unsigned)bf16_bits(c) | ((unsigned)bf16_bits(d) << 16));
+}
+
+// ybu != null (bf16 packed output, see ConvGemmArgs::yb): yu (may be null) gets the raw value, ybu the activated one
+// as bf16 in channel-group-major form.  For S == 1 a lane's four rows (r&3) are half of a channel group: one 8-byte
+// store; for transposed convs (S > 1) rows are (channel, phase) pairs and the bf16 values go out one by one.
 template <int BN>
 __device__ __forceinline__ void conv_epilogue_tile(const ConvGemmArgs &a, const f32x16 &acc, const float *Pm, int n0, int rbase,
-                                                   int m, float *yu, const float *ru, float *y2u) {
+                                                   int m, float *yu, const float *ru, float *y2u, unsigned short *ybu = nullptr) {
 #pragma unroll
     for (int half = 0; half < 2; half++) {
         long o[8];
@@ -153,7 +161,39 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvGemmArgs &a, const 
 #pragma unroll
             for (int q = 0; q < 8; q++) v[q] = fminf(fmaxf(v[q], -1.0f), 1.0f);
         }
-        if (a.psn_a) {
+        if (ybu) {
+            float w[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) w[q] = v[q];
+            if (a.psn_a) {
+#pragma unroll
+                for (int q = 0; q < 8; q += 2) {
+                    f32x2 sv = snake_beta2(mk2(v[q], v[q + 1]), mk2(Pm[2 * BN + row[q]], Pm[2 * BN + row[q + 1]]),
+                                           mk2(Pm[3 * BN + row[q]], Pm[3 * BN + row[q + 1]]));
+                    w[q] = sv.x; w[q + 1] = sv.y;
+                }
+            }
+            if (yu) {
+#pragma unroll
+                for (int q = 0; q < 8; q++)
+                    if (ok[q]) yu[o[q]] = v[q];
+            }
+            if (a.S == 1) {
+#pragma unroll
+                for (int g = 0; g < 2; g++) {      // rows row[4g..4g+3] = channels 4 consecutive, aligned to 4
+                    const int n = n0 + row[4 * g];
+                    if (ok[4 * g])                  // (N % 8 == 0: a half group is valid as a whole)
+                        *reinterpret_cast<uint2 *>(ybu + ((((long)(n >> 3) * a.y_cs + m) << 3) + (n & 4))) =
+                            pack4_bf16(w[4 * g], w[4 * g + 1], w[4 * g + 2], w[4 * g + 3]);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const int n = n0 + row[q], c = n / a.S, ph = n - c * a.S;
+                    if (ok[q]) ybu[(((long)(c >> 3) * a.y_cs + (long)m * a.S + ph) << 3) + (c & 7)] = bf16_bits(w[q]);
+                }
+            }
+        } else if (a.psn_a) {
             if (y2u) {
 #pragma unroll
                 for (int q = 0; q < 8; q += 2) {
@@ -183,7 +223,7 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvGemmArgs &a, const 
 // residual prefetched before the second product; parameters from the LDS table (rows rbase + ...).
 template <int BN>
 __device__ __forceinline__ void fused_epilogue_tile(const ConvGemmArgs &a, const f32x16 &acc2, const float *resv, const float *Pm,
-                                                    int rbase, int m, float *yu) {
+                                                    int rbase, int m, float *yu, unsigned short *ybu = nullptr) {
 #pragma unroll
     for (int half = 0; half < 2; half++) {
         int n[8];
@@ -192,6 +232,27 @@ __device__ __forceinline__ void fused_epilogue_tile(const ConvGemmArgs &a, const
         for (int q = 0; q < 8; q++) { const int r = half * 8 + q; n[q] = rbase + (r & 3) + 8 * (r >> 2); }
 #pragma unroll
         for (int q = 0; q < 8; q++) v[q] = resv[half * 8 + q] + (acc2[half * 8 + q] + Pm[3 * BN + n[q]]);
+        if (ybu) {     // raw fp32 to yu (if wanted), activated bf16 to the packed tensor
+            if (yu) {
+#pragma unroll
+                for (int q = 0; q < 8; q++)
+                    if (n[q] < a.N && m < a.M) yu[(long)n[q] * a.y_cs + m] = v[q];
+            }
+            if (a.psn_a) {
+#pragma unroll
+                for (int q = 0; q < 8; q += 2) {
+                    f32x2 sv = snake_beta2(mk2(v[q], v[q + 1]), mk2(Pm[4 * BN + n[q]], Pm[4 * BN + n[q + 1]]),
+                                           mk2(Pm[5 * BN + n[q]], Pm[5 * BN + n[q + 1]]));
+                    v[q] = sv.x; v[q + 1] = sv.y;
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 2; g++)
+                if (n[4 * g] < a.N && m < a.M)
+                    *reinterpret_cast<uint2 *>(ybu + ((((long)(n[4 * g] >> 3) * a.y_cs + m) << 3) + (n[4 * g] & 4))) =
+                        pack4_bf16(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+            continue;
+        }
         if (a.psn_a) {
 #pragma unroll
             for (int q = 0; q < 8; q += 2) {

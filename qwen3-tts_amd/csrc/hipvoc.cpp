@@ -96,6 +96,7 @@ struct Ctx {
     bool profile = false;
     bool fuse_res = true;
     bool post_snake = true;
+    bool packed = true;        // bf16 mode: GEMM-to-GEMM tensors of the decoder stack exchanged as packed bf16 (HIPVOC_PACKED=0: fp32)
     bool bf16 = false;         // HIPVOC_DTYPE_BF16: conv-GEMM operands in bf16, fp32 accumulate, everything else fp32
     int dual_out = 1;          // un-fused residual units, SnakeBeta in the producer's epilogue: 0 never, 1 conv7 -> conv1 only
                                // (no extra write), 2 also x / snake(x) written side by side (HIPVOC_DUAL)
@@ -529,7 +530,7 @@ static bool load_model(Ctx *c, const char *path, std::string &err) {
 
 // ---------------------------------------------------------------------------------------------
 // workspace + plan
-enum BufId { B_RVQ = 1, B_SUMS, B_PRE, B_H, B_XN, B_QKV, B_AO, B_GU, B_BIG0, B_BIG1, B_BIG2, B_SNK };
+enum BufId { B_RVQ = 1, B_SUMS, B_PRE, B_H, B_XN, B_QKV, B_AO, B_GU, B_BIG0, B_BIG1, B_BIG2, B_SNK, B_PK0, B_PK1 };
 
 struct PlanBuilder {
     Ctx *c;
@@ -567,9 +568,11 @@ struct PlanBuilder {
 
     // x[Cin][G][Lpi] -> y[N/S][G][Lpo]
     void gemm(const char *name, const Gemm &g, const float *x, int Lin, int Lpi, float *y, int Lpo, const Snake *sn,
-              const float *res, const float *rscale, int act, const Snake *post = nullptr, float *y2 = nullptr) {
+              const float *res, const float *rscale, int act, const Snake *post = nullptr, float *y2 = nullptr,
+              const unsigned short *xb = nullptr, unsigned short *yb = nullptr) {
         ConvGemmArgs a{};
         a.x = x; a.y = y; a.w = g.w; a.wb = g.wb; a.bias = g.bias; a.res = res; a.rscale = rscale; a.y2 = post ? y2 : nullptr;
+        a.xb = xb; a.yb = yb;
         a.psn_a = post ? post->ea : nullptr; a.psn_ib = post ? post->ib : nullptr;
         a.sn_a = sn ? sn->ea : nullptr; a.sn_ib = sn ? sn->ib : nullptr;
         a.Cin = g.Cin; a.N = g.N; a.NP = g.NP; a.TN = g.TN;
@@ -594,10 +597,12 @@ struct PlanBuilder {
                (c1.wb == nullptr || c2.wb2 != nullptr);
     }
     void res_unit_fused(const char *name, const Gemm &c1, const Gemm &c2, const Snake &s1, const Snake &s2, const float *x,
-                        int L, int Lp, float *y, const Snake *post) {
+                        int L, int Lp, float *y, const Snake *post, const unsigned short *xb = nullptr, unsigned short *yb = nullptr) {
         ConvGemmArgs a{};
         a.psn_a = post ? post->ea : nullptr; a.psn_ib = post ? post->ib : nullptr;
         a.x = x; a.y = y; a.w = c1.w; a.wb = c1.wb; a.bias = c1.bias; a.res = x; a.sn_a = s1.ea; a.sn_ib = s1.ib;
+        a.xb = xb; a.yb = yb;
+        if (xb) { a.sn_a = nullptr; a.sn_ib = nullptr; }      // the producer of xb already applied s1
         a.w2 = c2.w; a.wb2 = c2.wb2; a.bias2 = c2.bias; a.sn2_a = s2.ea; a.sn2_ib = s2.ib;
         a.Cin = c1.Cin; a.N = c1.N; a.NP = c1.NP; a.TN = c1.TN;
         a.ntaps = c1.ntaps; a.shift0 = c1.shift0; a.shift_step = c1.step; a.S = 1; a.act = ACT_NONE;
@@ -728,56 +733,115 @@ static Plan *get_plan(Ctx *c, int G, int T, bool debug = false) {
     // per row tile (up to 48x for block 0).  Debug plans (stage taps want the raw tensors) keep it in the
     // consumer.
     const bool post_snake = !debug && c->post_snake;
-    // g5
-    b.gemm("dec0_conv7", c->dec0, cur, L, Lp, t1, Lp, nullptr, nullptr, nullptr, ACT_NONE,
-           post_snake && !c->blocks.empty() ? &c->blocks[0].s : nullptr);
-    std::swap(cur, t1);
-    C = c->dec_dim;
-    b.mark(st++, cur, C, L, Lp);
-    // g6
-    static const char *tc_names[] = {"b0_transconv", "b1_transconv", "b2_transconv", "b3_transconv", "bN_transconv"};
-    static const char *c7_names[] = {"b0_conv7", "b1_conv7", "b2_conv7", "b3_conv7", "bN_conv7"};
-    static const char *ru_names[] = {"b0_resunit", "b1_resunit", "b2_resunit", "b3_resunit", "bN_resunit"};
-    static const char *c1_names[] = {"b0_conv1", "b1_conv1", "b2_conv1", "b3_conv1", "bN_conv1"};
-    for (size_t bi = 0; bi < c->blocks.size(); bi++) {
-        const Ctx::Block &blk = c->blocks[bi];
-        int r = c->rates[bi];
-        int L2 = (L - 1) * r, Lp2 = rup(L2, 4);
-        size_t ni = std::min<size_t>(bi, 4);
-        // Un-fused residual units (blocks whose channels do not fit one row tile): every SnakeBeta of the chain is
-        // evaluated by the PRODUCER of the tensor it acts on, once per element, instead of in the consumer's
-        // staging loop once per row tile: the trans-conv / the previous unit's conv1 write x (raw, the residual)
-        // and snake_s1(x) side by side; conv7 writes snake_s2(H) only.  Same fp32 operations on the same values,
-        // so results are bit-identical to the consumer-side form.
-        const bool fused_blk = blk_fused(blk);
-        const bool dual = c->dual_out >= 2 && !fused_blk;
-        const int Cn = blk.tc.N / r;
-        float *snk = dual ? snk_buf : nullptr;
-        b.gemm(tc_names[ni], blk.tc, cur, L, Lp, t1, Lp2, post_snake ? nullptr : &blk.s, nullptr, nullptr, ACT_NONE,
-               dual ? &blk.res[0].s1 : nullptr, snk);
-        std::swap(cur, t1);
-        L = L2; Lp = Lp2; C = Cn;
-        b.mark(st++, cur, C, L, Lp);
-        for (int u = 0; u < 3; u++) {
-            const Ctx::Res &ru = blk.res[u];
-            const Snake *post = (post_snake && u == 2 && bi + 1 < c->blocks.size()) ? &c->blocks[bi + 1].s : nullptr;
-            if (fused_blk) {
-                b.res_unit_fused(ru_names[ni], ru.c1, ru.c2, ru.s1, ru.s2, cur, L, Lp, t1, post);
-                std::swap(cur, t1);
-            } else if (dual) {
-                b.gemm(c7_names[ni], ru.c1, snk, L, Lp, t1, Lp, nullptr, nullptr, nullptr, ACT_NONE, &ru.s2);
-                if (u < 2)
-                    b.gemm(c1_names[ni], ru.c2, t1, L, Lp, cur, Lp, nullptr, cur, nullptr, ACT_NONE, &blk.res[u + 1].s1, snk);
-                else
-                    b.gemm(c1_names[ni], ru.c2, t1, L, Lp, cur, Lp, nullptr, cur, nullptr, ACT_NONE, post);
-            } else if (c->dual_out == 1) {
-                b.gemm(c7_names[ni], ru.c1, cur, L, Lp, t1, Lp, &ru.s1, nullptr, nullptr, ACT_NONE, &ru.s2);
-                b.gemm(c1_names[ni], ru.c2, t1, L, Lp, cur, Lp, nullptr, cur, nullptr, ACT_NONE, post);
-            } else {
-                b.gemm(c7_names[ni], ru.c1, cur, L, Lp, t1, Lp, &ru.s1, nullptr, nullptr, ACT_NONE);
-                b.gemm(c1_names[ni], ru.c2, t1, L, Lp, cur, Lp, &ru.s2, cur, nullptr, ACT_NONE, post);
-            }
+    // bf16 mode: every tensor of the decoder stack that is only consumed as a GEMM operand is
+    // exchanged as packed bf16 with the consumer's SnakeBeta applied by its producer (ConvGemmArgs::xb / yb); the
+    // residual stream stays fp32.  Needs every channel count of the stack to be a multiple of 8.
+    bool packed = c->bf16 && c->packed && !c->blocks.empty() && c->dec_dim % 8 == 0;
+    for (size_t i = 0; packed && i < c->blocks.size(); i++) packed = (c->blocks[i].tc.N / c->rates[i]) % 8 == 0;
+    if (packed) {
+        unsigned short *pk[2] = {reinterpret_cast<unsigned short *>(b.buf(B_PK0, big / 2 + 64)),
+                                 reinterpret_cast<unsigned short *>(b.buf(B_PK1, big / 2 + 64))};
+        if (b.fail || !pk[0] || !pk[1]) return nullptr;
+        int pc = 0;                                   // pk[pc] holds the current packed tensor
+        // (debug plans additionally write every raw fp32 tensor, for the stage taps)
+        b.gemm("dec0_conv7", c->dec0, cur, L, Lp, debug ? t1 : nullptr, Lp, nullptr, nullptr, nullptr, ACT_NONE, &c->blocks[0].s,
+               nullptr, nullptr, pk[pc]);
+        if (debug) std::swap(cur, t1);
+        C = c->dec_dim;
+        if (debug) b.mark(st, cur, C, L, Lp);
+        st++;
+        static const char *tcn[] = {"b0_transconv", "b1_transconv", "b2_transconv", "b3_transconv", "bN_transconv"};
+        static const char *c7n[] = {"b0_conv7", "b1_conv7", "b2_conv7", "b3_conv7", "bN_conv7"};
+        static const char *run[] = {"b0_resunit", "b1_resunit", "b2_resunit", "b3_resunit", "bN_resunit"};
+        static const char *c1n[] = {"b0_conv1", "b1_conv1", "b2_conv1", "b3_conv1", "bN_conv1"};
+        for (size_t bi = 0; bi < c->blocks.size(); bi++) {
+            const Ctx::Block &blk = c->blocks[bi];
+            const int r = c->rates[bi];
+            const int L2 = (L - 1) * r, Lp2 = rup(L2, 4);
+            const size_t ni = std::min<size_t>(bi, 4);
+            const bool fused_blk = blk_fused(blk);
+            // trans-conv: packed in; fp32 x0 (the residual stream) and packed snake_s1(x0) out
+            b.gemm(tcn[ni], blk.tc, nullptr, L, Lp, t1, Lp2, nullptr, nullptr, nullptr, ACT_NONE, &blk.res[0].s1, nullptr, pk[pc],
+                   pk[pc ^ 1]);
+            std::swap(cur, t1);
+            pc ^= 1;
+            L = L2; Lp = Lp2; C = blk.tc.N / r;
             b.mark(st++, cur, C, L, Lp);
+            for (int u = 0; u < 3; u++) {
+                const Ctx::Res &ru = blk.res[u];
+                const bool last = u == 2 && bi + 1 == c->blocks.size();      // feeds the final conv: fp32 only
+                const Snake *next = u < 2 ? &blk.res[u + 1].s1 : (last ? nullptr : &c->blocks[bi + 1].s);
+                const bool need_f32 = u < 2 || last || debug;                // the residual stream goes on / the final conv
+                if (fused_blk) {
+                    unsigned short *ybo = last ? nullptr : pk[pc ^ 1];
+                    b.res_unit_fused(run[ni], ru.c1, ru.c2, ru.s1, ru.s2, cur, L, Lp, need_f32 ? t1 : nullptr, next, pk[pc], ybo);
+                    if (need_f32) std::swap(cur, t1);
+                    if (ybo) pc ^= 1;
+                } else {
+                    b.gemm(c7n[ni], ru.c1, nullptr, L, Lp, nullptr, Lp, nullptr, nullptr, nullptr, ACT_NONE, &ru.s2, nullptr, pk[pc],
+                           pk[pc ^ 1]);
+                    pc ^= 1;
+                    unsigned short *ybo = last ? nullptr : pk[pc ^ 1];      // (the unit's input: no longer needed)
+                    b.gemm(c1n[ni], ru.c2, nullptr, L, Lp, need_f32 ? cur : nullptr, Lp, nullptr, cur, nullptr, ACT_NONE, next, nullptr,
+                           pk[pc], ybo);
+                    if (ybo) pc ^= 1;
+                }
+                if (need_f32) b.mark(st, cur, C, L, Lp);
+                st++;
+            }
+        }
+    } else {
+        // g5
+        b.gemm("dec0_conv7", c->dec0, cur, L, Lp, t1, Lp, nullptr, nullptr, nullptr, ACT_NONE,
+               post_snake && !c->blocks.empty() ? &c->blocks[0].s : nullptr);
+        std::swap(cur, t1);
+        C = c->dec_dim;
+        b.mark(st++, cur, C, L, Lp);
+        // g6
+        static const char *tc_names[] = {"b0_transconv", "b1_transconv", "b2_transconv", "b3_transconv", "bN_transconv"};
+        static const char *c7_names[] = {"b0_conv7", "b1_conv7", "b2_conv7", "b3_conv7", "bN_conv7"};
+        static const char *ru_names[] = {"b0_resunit", "b1_resunit", "b2_resunit", "b3_resunit", "bN_resunit"};
+        static const char *c1_names[] = {"b0_conv1", "b1_conv1", "b2_conv1", "b3_conv1", "bN_conv1"};
+        for (size_t bi = 0; bi < c->blocks.size(); bi++) {
+            const Ctx::Block &blk = c->blocks[bi];
+            int r = c->rates[bi];
+            int L2 = (L - 1) * r, Lp2 = rup(L2, 4);
+            size_t ni = std::min<size_t>(bi, 4);
+            // Un-fused residual units (blocks whose channels do not fit one row tile): every SnakeBeta of the chain is
+            // evaluated by the PRODUCER of the tensor it acts on, once per element, instead of in the consumer's
+            // staging loop once per row tile: the trans-conv / the previous unit's conv1 write x (raw, the residual)
+            // and snake_s1(x) side by side; conv7 writes snake_s2(H) only.  Same fp32 operations on the same values,
+            // so results are bit-identical to the consumer-side form.
+            const bool fused_blk = blk_fused(blk);
+            const bool dual = c->dual_out >= 2 && !fused_blk;
+            const int Cn = blk.tc.N / r;
+            float *snk = dual ? snk_buf : nullptr;
+            b.gemm(tc_names[ni], blk.tc, cur, L, Lp, t1, Lp2, post_snake ? nullptr : &blk.s, nullptr, nullptr, ACT_NONE,
+                   dual ? &blk.res[0].s1 : nullptr, snk);
+            std::swap(cur, t1);
+            L = L2; Lp = Lp2; C = Cn;
+            b.mark(st++, cur, C, L, Lp);
+            for (int u = 0; u < 3; u++) {
+                const Ctx::Res &ru = blk.res[u];
+                const Snake *post = (post_snake && u == 2 && bi + 1 < c->blocks.size()) ? &c->blocks[bi + 1].s : nullptr;
+                if (fused_blk) {
+                    b.res_unit_fused(ru_names[ni], ru.c1, ru.c2, ru.s1, ru.s2, cur, L, Lp, t1, post);
+                    std::swap(cur, t1);
+                } else if (dual) {
+                    b.gemm(c7_names[ni], ru.c1, snk, L, Lp, t1, Lp, nullptr, nullptr, nullptr, ACT_NONE, &ru.s2);
+                    if (u < 2)
+                        b.gemm(c1_names[ni], ru.c2, t1, L, Lp, cur, Lp, nullptr, cur, nullptr, ACT_NONE, &blk.res[u + 1].s1, snk);
+                    else
+                        b.gemm(c1_names[ni], ru.c2, t1, L, Lp, cur, Lp, nullptr, cur, nullptr, ACT_NONE, post);
+                } else if (c->dual_out == 1) {
+                    b.gemm(c7_names[ni], ru.c1, cur, L, Lp, t1, Lp, &ru.s1, nullptr, nullptr, ACT_NONE, &ru.s2);
+                    b.gemm(c1_names[ni], ru.c2, t1, L, Lp, cur, Lp, nullptr, cur, nullptr, ACT_NONE, post);
+                } else {
+                    b.gemm(c7_names[ni], ru.c1, cur, L, Lp, t1, Lp, &ru.s1, nullptr, nullptr, ACT_NONE);
+                    b.gemm(c1_names[ni], ru.c2, t1, L, Lp, cur, Lp, &ru.s2, cur, nullptr, ACT_NONE, post);
+                }
+                b.mark(st++, cur, C, L, Lp);
+            }
         }
     }
     // g7: final snake + conv -> 1 channel + clamp, written straight to the caller's buffer
@@ -972,6 +1036,7 @@ void *hipvoc_load(const char *weights_path, int device_id, int dtype, int unit_f
     if (const char *fz = getenv("HIPVOC_FUSE")) c->fuse_res = atoi(fz) != 0;
     if (const char *ps = getenv("HIPVOC_POST_SNAKE")) c->post_snake = atoi(ps) != 0;
     if (const char *ps = getenv("HIPVOC_DUAL")) c->dual_out = atoi(ps);
+    if (const char *ps = getenv("HIPVOC_PACKED")) c->packed = atoi(ps) != 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
     std::string err;
     if (!load_model(c.get(), weights_path, err)) return fail(err);

@@ -38,6 +38,14 @@ struct ConvGemmArgs {
     // [2*NP/32 k-steps][2][32][8] bf16 in the k order of the accumulator registers (hipvoc.cpp)
     const unsigned short *wb;
     const unsigned short *wb2;
+    // bf16 mode, packed activations (optional): tensors that are only ever consumed as GEMM operands are exchanged
+    // as bf16 in channel-group-major form -- 16-byte element (c/8, u, t) at index (c/8)*cs + u*us + t, i.e. the
+    // strides of the fp32 layout counted in 16-byte elements -- with the consumer's SnakeBeta already applied by
+    // the producer.  xb: this conv's input in that form (x is then unused; needs Cin % 8 == 0, no sn_*).
+    // yb: also write act(out) in that form, act = psn_* if given else identity (y then keeps the RAW fp32 value and
+    // may be null when nobody needs it; y2 is not used together with yb; needs (N/S) % 8 == 0).
+    const unsigned short *xb;
+    unsigned short *yb;
     int Cin, N, NP, TN;
     int ntaps, shift0, shift_step;   // shift(tap) = shift0 + tap*shift_step
     int S;                           // out channel = n / S, out position = m*S + n % S

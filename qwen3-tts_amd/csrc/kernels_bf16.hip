@@ -39,7 +39,9 @@ __device__ __forceinline__ bf16x8 pack8(const f32x8 &v) {
     return o;
 }
 
-template <int TN, bool FUSE>
+// XB: the input is a packed bf16 tensor (ConvGemmArgs::xb, activation already applied by its producer): staging a
+// (k-group, position) pair is ONE 16-byte load and one 16-byte LDS store -- no gather, no SnakeBeta, no conversion.
+template <int TN, bool FUSE, bool XB>
 __global__ __launch_bounds__(NTHB, (TN > 4) ? 2 : 4) void conv_gemm_bf16_kernel(ConvGemmArgs a, int HL, int XW,
                                                                                  int tiles_per_unit, int n_tiles) {
     constexpr int BN = TN * 32;
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(NTHB, (TN > 4) ? 2 : 4) void conv_gemm_bf16_kernel(
     const int nstage = ncb * a.ntaps;
 
     fill_param_table<BN, FUSE>(a, Pm, n0, tid, NTHB);           // read after the main loop (barriers in between)
-    if (a.sn_a) {
+    if (!XB && a.sn_a) {
         for (int i = tid; i < CinP; i += NTHB) {
             Sn[i] = i < a.Cin ? a.sn_a[i] : 0.0f;
             Sn[CinP + i] = i < a.Cin ? a.sn_ib[i] : 0.0f;
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(NTHB, (TN > 4) ? 2 : 4) void conv_gemm_bf16_kernel(
             bool ok = pos >= 0 && pos < a.Lin;
             pos = pos < 0 ? 0 : (pos >= a.Lin ? a.Lin - 1 : pos);
             bool ex = kq < 4;
-            off = (unsigned)((ex ? kq : 0) * 8) * (unsigned)a.x_cs + (unsigned)pos;
+            off = (unsigned)((ex ? kq : 0) * (XB ? 1 : 8)) * (unsigned)a.x_cs + (unsigned)pos;
             xmeta |= (unsigned)((ex ? kq : 0) | (ex ? 4 : 0) | (ok ? 8 : 0)) << (4 * round);
         };
         prep(0, offa); prep(1, offb); prep(2, offc);
@@ -170,8 +172,42 @@ __global__ __launch_bounds__(NTHB, (TN > 4) ? 2 : 4) void conv_gemm_bf16_kernel(
         }
         Xs[buf * 4 * XW + tid + round * NTHB] = pack8(v);
     };
-#define X_FETCH(cb_) { xa = x_fetch1(cb_, 0, offa); xb = x_fetch1(cb_, 1, offb); xc = x_fetch1(cb_, 2, offc); }
-#define X_COMMIT(cb_, buf_) { x_commit1(cb_, buf_, 0, xa); x_commit1(cb_, buf_, 1, xb); x_commit1(cb_, buf_, 2, xc); }
+    // packed input: element (k-group cb*4+kq, unit, pos) of a.xb; the descriptor ends after the last real group
+    uint4 qa = make_uint4(0, 0, 0, 0), qb = qa, qc = qa;
+    const int ngroups = (a.Cin + 7) >> 3;
+    auto xq_fetch1 = [&](int cb, int round, unsigned off) -> uint4 {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        const unsigned m = xmeta >> (4 * round);
+        if (m & 4) {
+            const long groups_left = ngroups - cb * 4;
+            const long bytes = groups_left * a.x_cs * 16;
+            const unsigned long long ba = reinterpret_cast<unsigned long long>(a.xb) + ((unsigned long long)((long)unit * a.x_us + (long)cb * 4 * a.x_cs) << 4);
+            const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)ba), bhi = __builtin_amdgcn_readfirstlane((unsigned)(ba >> 32));
+            const int nrec = __builtin_amdgcn_readfirstlane(bytes < 0x7fffffffL ? (int)bytes : 0x7fffffff);
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                reinterpret_cast<void *>(((unsigned long long)bhi << 32) | blo), 0, nrec, 0x00020000);
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rs, off * 16u, 0, 0);
+            v = make_uint4(r[0], r[1], r[2], r[3]);
+        }
+        return v;
+    };
+    auto xq_commit1 = [&](int buf, int round, uint4 v) {
+        const unsigned m = xmeta >> (4 * round);
+        if (!(m & 4)) return;
+        if (!(m & 8)) v = make_uint4(0, 0, 0, 0);
+        reinterpret_cast<uint4 *>(Xs)[buf * 4 * XW + tid + round * NTHB] = v;
+    };
+#define X_FETCH(cb_)                                                                                              \
+    {                                                                                                             \
+        if constexpr (XB) { qa = xq_fetch1(cb_, 0, offa); qb = xq_fetch1(cb_, 1, offb); qc = xq_fetch1(cb_, 2, offc); } \
+        else { xa = x_fetch1(cb_, 0, offa); xb = x_fetch1(cb_, 1, offb); xc = x_fetch1(cb_, 2, offc); }             \
+    }
+#define X_COMMIT(cb_, buf_)                                                                                       \
+    {                                                                                                             \
+        if constexpr (XB) { xq_commit1(buf_, 0, qa); xq_commit1(buf_, 1, qb); xq_commit1(buf_, 2, qc); }            \
+        else { x_commit1(cb_, buf_, 0, xa); x_commit1(cb_, buf_, 1, xb); x_commit1(cb_, buf_, 2, xc); }             \
+    }
 
     X_FETCH(0)
     W_LOAD(0);
@@ -248,7 +284,8 @@ __global__ __launch_bounds__(NTHB, (TN > 4) ? 2 : 4) void conv_gemm_bf16_kernel(
 #pragma unroll
                 for (int j = 0; j < 8; j++) hb[i][g][j] = (__bf16)acc[i][8 * g + j];
         }
-        float *yu = a.y + (long)unit * a.y_us;
+        float *yu = a.y ? a.y + (long)unit * a.y_us : nullptr;
+        unsigned short *ybu = a.yb ? a.yb + (((long)unit * a.y_us) << 3) : nullptr;
         const int m = m0 + wave * 32 + l31;
         uint4 *w2s = reinterpret_cast<uint4 *>(smem_raw);
         __syncthreads();                          // every wave is done with the main loop's tiles
@@ -287,20 +324,22 @@ __global__ __launch_bounds__(NTHB, (TN > 4) ? 2 : 4) void conv_gemm_bf16_kernel(
                 if constexpr (W2N > NTHB) if (tid + NTHB < W2N) wd_[tid + NTHB] = w1;
             }
             dep2 = acc2[15];
-            fused_epilogue_tile<BN>(a, acc2, resv, Pm, o * 32 + 4 * h, m, yu);
+            fused_epilogue_tile<BN>(a, acc2, resv, Pm, o * 32 + 4 * h, m, yu, ybu);
         }
         return;
     }
 
     // epilogue (fp32): bias, activation, per-channel scale, residual, optional SnakeBeta, store
-    float *yu = a.y + (long)unit * a.y_us;
+    float *yu = a.y ? a.y + (long)unit * a.y_us : nullptr;
     const float *ru0 = launder_after(a.res, acc[TN - 1][15]);
     const float *ru = ru0 ? ru0 + (long)unit * a.y_us : nullptr;
     float *y2u0 = launder_after(a.y2, acc[TN - 1][15]);
     float *y2u = y2u0 ? y2u0 + (long)unit * a.y_us : nullptr;
     const int m = m0 + wave * 32 + l31;
+    unsigned short *ybu0 = launder_after(a.yb, acc[TN - 1][15]);
+    unsigned short *ybu = ybu0 ? ybu0 + (((long)unit * a.y_us) << 3) : nullptr;
 #pragma unroll
-    for (int i = 0; i < TN; i++) conv_epilogue_tile<BN>(a, acc[i], Pm, n0, i * 32 + 4 * h, m, yu, ru, y2u);
+    for (int i = 0; i < TN; i++) conv_epilogue_tile<BN>(a, acc[i], Pm, n0, i * 32 + 4 * h, m, yu, ru, y2u, ybu);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -316,15 +355,15 @@ size_t conv_gemm_bf16_lds_bytes(const ConvGemmArgs &a) {
 }
 
 const char *conv_gemm_bf16_kernel_name(const ConvGemmArgs &a) {
-    static char names[2][8][48];
+    static char names[2][2][8][56];
     int tn = detail::conv_gemm_launch_tn(a);
-    int fuse = a.wb2 ? 1 : 0;
-    char *n = names[fuse][tn & 7];
-    if (!n[0]) snprintf(n, 48, "conv_gemm_bf16_kernel<%d,%s>", tn, fuse ? "true" : "false");
+    int fuse = a.wb2 ? 1 : 0, xbf = a.xb ? 1 : 0;
+    char *n = names[fuse][xbf][tn & 7];
+    if (!n[0]) snprintf(n, 56, "conv_gemm_bf16_kernel<%d,%s,%s>", tn, fuse ? "true" : "false", xbf ? "true" : "false");
     return n;
 }
 
-template <int TN, bool FUSE>
+template <int TN, bool FUSE, bool XB>
 static hipError_t launch_one_bf16(const ConvGemmArgs &a, int HL, int XW, int tiles_per_unit, int n_tiles, long grid,
                                   size_t lds, hipStream_t s) {
     static bool done[64] = {};
@@ -332,12 +371,12 @@ static hipError_t launch_one_bf16(const ConvGemmArgs &a, int HL, int XW, int til
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 64 && !done[dev]) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_gemm_bf16_kernel<TN, FUSE>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_gemm_bf16_kernel<TN, FUSE, XB>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         done[dev] = true;
     }
-    hipLaunchKernelGGL((conv_gemm_bf16_kernel<TN, FUSE>), dim3((unsigned)grid), dim3(NTHB), lds, s, a, HL, XW,
+    hipLaunchKernelGGL((conv_gemm_bf16_kernel<TN, FUSE, XB>), dim3((unsigned)grid), dim3(NTHB), lds, s, a, HL, XW,
                        tiles_per_unit, n_tiles);
     return hipGetLastError();
 }
@@ -358,7 +397,10 @@ hipError_t launch_conv_gemm_bf16(const ConvGemmArgs &a_in, hipStream_t s) {
         (long)a.x_cs * 4 * (BKB + 1) >= 0x7fffffffL)   // 32-bit byte offsets of the buffer loads (a channel block + a row)
         return hipErrorInvalidValue;
     const int tn = detail::conv_gemm_launch_tn(a);
-    if (a.y2 && (!a.psn_a || !a.psn_ib || a.wb2)) return hipErrorInvalidValue;
+    if (a.y2 && (!a.psn_a || !a.psn_ib || a.wb2 || a.yb)) return hipErrorInvalidValue;
+    if (a.xb && ((a.Cin & 7) || a.sn_a || ((uintptr_t)a.xb & 15) || (long)a.x_cs * 16 * 5 >= 0x7fffffffL)) return hipErrorInvalidValue;
+    if (a.yb && (((a.N / a.S) & 7) || (a.N % a.S) || ((uintptr_t)a.yb & 15))) return hipErrorInvalidValue;
+    if (!a.y && !a.yb) return hipErrorInvalidValue;
     if (a.wb2 && (a.S != 1 || a.NP != 32 * tn || (a.N + 31) / 32 != tn || tn == 5 || tn > 6 || !a.res || !a.sn2_a ||
                   !a.sn2_ib || !a.bias || !a.bias2 || ((uintptr_t)a.wb2 & 15)))
         return hipErrorInvalidValue;
@@ -368,23 +410,24 @@ hipError_t launch_conv_gemm_bf16(const ConvGemmArgs &a_in, hipStream_t s) {
     if (grid > 0x7fffffffL) return hipErrorInvalidValue;
     size_t lds = conv_gemm_bf16_lds_bytes(a);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-#define GO(TN_, F_) return launch_one_bf16<TN_, F_>(a, HL, XW, tiles_per_unit, n_tiles, grid, lds, s)
+#define GOX(TN_, F_, X_) return launch_one_bf16<TN_, F_, X_>(a, HL, XW, tiles_per_unit, n_tiles, grid, lds, s)
+#define SW(F_, X_)                  \
+    switch (tn) {                   \
+        case 1: GOX(1, F_, X_);     \
+        case 2: GOX(2, F_, X_);     \
+        case 3: GOX(3, F_, X_);     \
+        case 4: GOX(4, F_, X_);     \
+        default: break;             \
+    }
     if (a.wb2) {
-        switch (tn) {
-            case 1: GO(1, true);
-            case 2: GO(2, true);
-            case 3: GO(3, true);
-            case 4: GO(4, true);
-            default: GO(6, true);
-        }
+        if (a.xb) { SW(true, true) GOX(6, true, true); }
+        SW(true, false) GOX(6, true, false);
     }
-    switch (tn) {
-        case 1: GO(1, false);
-        case 2: GO(2, false);
-        case 3: GO(3, false);
-        default: GO(4, false);
-    }
-#undef GO
+    if (a.xb) { SW(false, true) }
+    SW(false, false)
+    return hipErrorInvalidValue;
+#undef GOX
+#undef SW
 }
 
 }  // namespace hipvoc

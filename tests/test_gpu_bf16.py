@@ -130,3 +130,30 @@ def test_bf16_deterministic(pkg, synth):
     a = v.run(codes)
     b = v.run(codes)
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.mark.parametrize("cfg_name,unit,frames", [("SMALL", 4, 10), ("FULL", 8, 8)])
+def test_bf16_packed_dataflow_equals_fp32_exchange_bitwise(pkg, synth, cfg_name, unit, frames):
+    """Production bf16 plans exchange GEMM-to-GEMM tensors of the decoder stack as packed bf16 with the consumer's
+    SnakeBeta applied by the producer (ConvGemmArgs::xb / yb); HIPVOC_PACKED=0 keeps them fp32 and rounds in the
+    consumer.  Same fp32 values rounded at the same point: the waveforms must be identical."""
+    cfg = getattr(synth, cfg_name)
+    path = os.path.join(tempfile.gettempdir(), f"hipvoc_test_{cfg_name}_0.safetensors")
+    if not os.path.exists(path):
+        synth.save_safetensors(path, weights_for(synth, cfg_name, 0), cfg.metadata())
+    codes = synth.make_codes(frames, 11, cfg)
+    old = os.environ.get("HIPVOC_PACKED")
+    try:
+        os.environ["HIPVOC_PACKED"] = "0"
+        plain = pkg.HipVocoder.load(path, device=0, unit_frames=unit, dtype=BF16)
+        os.environ["HIPVOC_PACKED"] = "1"
+        packed = pkg.HipVocoder.load(path, device=0, unit_frames=unit, dtype=BF16)
+    finally:
+        if old is None:
+            os.environ.pop("HIPVOC_PACKED", None)
+        else:
+            os.environ["HIPVOC_PACKED"] = old
+    a = plain.synthesize(codes)
+    b = packed.synthesize(codes)
+    assert a.size == b.size and a.size > 0
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), float(np.abs(a - b).max())
