@@ -87,7 +87,7 @@ template <int BN, bool FUSE>
 __device__ __forceinline__ void fill_param_table(const ConvGemmArgs &a, float *Pm, int n0, int tid, int nthreads) {
     for (int row = tid; row < BN; row += nthreads) {
         const int n = n0 + row;
-        const int co = a.S > 1 ? n / a.S : n;
+        const int co = a.S > 1 ? (a.pm ? n % (a.N / a.S) : n / a.S) : n;
         if constexpr (FUSE) {
             Pm[0 * BN + row] = a.bias[co];
             Pm[1 * BN + row] = a.sn2_a[co];
@@ -115,7 +115,8 @@ __device__ __forceinline__ uint2 pack4_bf16(float a, float b, float c, float d) 
 
 // ybu != null (bf16 packed output, see ConvGemmArgs::yb): yu (may be null) gets the raw value, ybu the activated one
 // as bf16 in channel-group-major form.  For S == 1 a lane's four rows (r&3) are half of a channel group: one 8-byte
-// store; for transposed convs (S > 1) rows are (channel, phase) pairs and the bf16 values go out one by one.
+// store; the same holds for transposed convs with phase-major rows (ConvGemmArgs::pm); with channel-major rows
+// (channel, phase) pairs the bf16 values go out one by one.
 template <int BN>
 __device__ __forceinline__ void conv_epilogue_tile(const ConvGemmArgs &a, const f32x16 &acc, const float *Pm, int n0, int rbase,
                                                    int m, float *yu, const float *ru, float *y2u, unsigned short *ybu = nullptr) {
@@ -124,6 +125,14 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvGemmArgs &a, const 
         long o[8];
         bool ok[8];
         int row[8];
+        int cg[2] = {0, 0}, pg[2] = {0, 0};      // (channel, phase) of rows row[0] and row[4] (grouped forms)
+        if (a.S > 1 && a.pm) {                   // phase-major rows: one division per half tile; a lane's four
+            const int Co = a.N / a.S;            // consecutive rows are four channels of ONE phase (Co % 8 == 0)
+            const int n = n0 + rbase + 16 * half;
+            pg[0] = n / Co; cg[0] = n - pg[0] * Co;
+            cg[1] = cg[0] + 8; pg[1] = pg[0];
+            if (cg[1] >= Co) { cg[1] -= Co; pg[1]++; }
+        }
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             const int r = half * 8 + q;
@@ -131,9 +140,13 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvGemmArgs &a, const 
             const int n = n0 + row[q];
             ok[q] = n < a.N && m < a.M;
             int c = n, ph = 0;
-            if (a.S > 1) { c = n / a.S; ph = n - c * a.S; }
+            if (a.S > 1) {
+                if (a.pm) { c = cg[q >> 2] + (q & 3); ph = pg[q >> 2]; }
+                else { c = n / a.S; ph = n - c * a.S; }
+            }
             o[q] = (long)c * a.y_cs + (long)m * a.S + ph;
         }
+        if (a.S == 1) { cg[0] = n0 + row[0]; cg[1] = n0 + row[4]; }
         float v[8], t[8];
 #pragma unroll
         for (int q = 0; q < 8; q++) v[q] = acc[half * 8 + q];
@@ -178,12 +191,12 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvGemmArgs &a, const 
                 for (int q = 0; q < 8; q++)
                     if (ok[q]) yu[o[q]] = v[q];
             }
-            if (a.S == 1) {
+            if (a.S == 1 || a.pm) {
 #pragma unroll
                 for (int g = 0; g < 2; g++) {      // rows row[4g..4g+3] = channels 4 consecutive, aligned to 4
-                    const int n = n0 + row[4 * g];
-                    if (ok[4 * g])                  // (N % 8 == 0: a half group is valid as a whole)
-                        *reinterpret_cast<uint2 *>(ybu + ((((long)(n >> 3) * a.y_cs + m) << 3) + (n & 4))) =
+                    const int c = cg[g];
+                    if (ok[4 * g])                  // ((N/S) % 8 == 0: a half group is valid as a whole)
+                        *reinterpret_cast<uint2 *>(ybu + ((((long)(c >> 3) * a.y_cs + (long)m * a.S + pg[g]) << 3) + (c & 4))) =
                             pack4_bf16(w[4 * g], w[4 * g + 1], w[4 * g + 2], w[4 * g + 3]);
                 }
             } else {

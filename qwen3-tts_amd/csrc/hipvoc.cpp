@@ -50,6 +50,7 @@ struct Gemm {
     unsigned short *wb2 = nullptr;   // bf16 mode, 1x1 conv of a fusable residual unit: accumulator-order packing
     float *bias = nullptr;   // device [N/S] or null
     int Cin = 0, N = 0, NP = 0, TN = 0, ntaps = 1, shift0 = 0, step = 0, S = 1;
+    int pm = 0;              // transposed conv: rows are phase-major (n = phase * Cout + channel), see ConvGemmArgs::pm
 };
 
 static const char *gemm_kernel_name(int tn) {
@@ -96,6 +97,7 @@ struct Ctx {
     bool profile = false;
     bool fuse_res = true;
     bool post_snake = true;
+    bool phase_major = true;   // bf16 mode: transposed-conv rows phase-major (HIPVOC_PHASE_MAJOR=0: channel-major)
     bool packed = true;        // bf16 mode: GEMM-to-GEMM tensors of the decoder stack exchanged as packed bf16 (HIPVOC_PACKED=0: fp32)
     bool bf16 = false;         // HIPVOC_DTYPE_BF16: conv-GEMM operands in bf16, fp32 accumulate, everything else fp32
     int dual_out = 1;          // un-fused residual units, SnakeBeta in the producer's epilogue: 0 never, 1 conv7 -> conv1 only
@@ -342,16 +344,20 @@ struct Loader {
         int Cin = (int)sh[0], Co = (int)sh[1], K = (int)sh[2];
         g.Cin = Cin; g.N = Co * s; g.TN = pick_tn(g.N); g.NP = rup(g.N, 32 * g.TN);
         g.ntaps = K / s; g.shift0 = 0; g.step = 1; g.S = s;
+        // bf16 mode: phase-major rows, so that a lane's four consecutive accumulator rows are four channels of one
+        // output position (8-byte stores into the packed bf16 tensors instead of four 2-byte ones)
+        g.pm = c->bf16 && c->phase_major && s > 1 && Co % 8 == 0;
         int CinP = rup(Cin, 32);
         std::vector<float> p((size_t)g.ntaps * CinP * g.NP, 0.0f);
         for (int ci = 0; ci < Cin; ci++)
             for (int co = 0; co < Co; co++)
                 for (int r = 0; r < s; r++) {
+                    const int n = g.pm ? r * Co + co : co * s + r;
                     if (K == s) {
-                        p[((size_t)ci) * g.NP + co * s + r] = w[((size_t)ci * Co + co) * K + r];
+                        p[((size_t)ci) * g.NP + n] = w[((size_t)ci * Co + co) * K + r];
                     } else {
-                        p[((size_t)0 * CinP + ci) * g.NP + co * s + r] = w[((size_t)ci * Co + co) * K + r + s];
-                        p[((size_t)1 * CinP + ci) * g.NP + co * s + r] = w[((size_t)ci * Co + co) * K + r];
+                        p[((size_t)0 * CinP + ci) * g.NP + n] = w[((size_t)ci * Co + co) * K + r + s];
+                        p[((size_t)1 * CinP + ci) * g.NP + n] = w[((size_t)ci * Co + co) * K + r];
                     }
                 }
         finish(g, p, CinP);
@@ -576,7 +582,7 @@ struct PlanBuilder {
         a.psn_a = post ? post->ea : nullptr; a.psn_ib = post ? post->ib : nullptr;
         a.sn_a = sn ? sn->ea : nullptr; a.sn_ib = sn ? sn->ib : nullptr;
         a.Cin = g.Cin; a.N = g.N; a.NP = g.NP; a.TN = g.TN;
-        a.ntaps = g.ntaps; a.shift0 = g.shift0; a.shift_step = g.step; a.S = g.S; a.act = act;
+        a.ntaps = g.ntaps; a.shift0 = g.shift0; a.shift_step = g.step; a.S = g.S; a.pm = g.pm; a.act = act;
         int M = g.S > 1 ? (g.ntaps == 2 ? Lin - 1 : Lin) : Lin;
         bool flat = g.ntaps == 1 && (g.S == 1 ? Lpi == Lpo : Lpo == g.S * Lpi);
         if (flat) {
@@ -1037,6 +1043,7 @@ void *hipvoc_load(const char *weights_path, int device_id, int dtype, int unit_f
     if (const char *ps = getenv("HIPVOC_POST_SNAKE")) c->post_snake = atoi(ps) != 0;
     if (const char *ps = getenv("HIPVOC_DUAL")) c->dual_out = atoi(ps);
     if (const char *ps = getenv("HIPVOC_PACKED")) c->packed = atoi(ps) != 0;
+    if (const char *ps = getenv("HIPVOC_PHASE_MAJOR")) c->phase_major = atoi(ps) != 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
     std::string err;
     if (!load_model(c.get(), weights_path, err)) return fail(err);

@@ -49,6 +49,7 @@ struct ConvGemmArgs {
     int Cin, N, NP, TN;
     int ntaps, shift0, shift_step;   // shift(tap) = shift0 + tap*shift_step
     int S;                           // out channel = n / S, out position = m*S + n % S
+    int pm;                          // S > 1, phase-major rows instead: out channel = n % (N/S), phase = n / (N/S); needs (N/S) % 8 == 0
     int units;                       // G (1 in flat mode)
     int M;                           // GEMM columns per unit
     int Lin;                         // valid input positions per unit
