@@ -6,4 +6,5 @@ The directory name carries a hyphen (it mirrors the reference's name), so import
 from . import sharding, synth  # noqa: F401
 from . import hipvoc  # noqa: F401
 from . import wire  # noqa: F401
+from . import voice  # noqa: F401
 from .hipvoc import HipVocoder, HipVocError, lib_path, load_library  # noqa: F401

@@ -141,3 +141,24 @@ def test_worker_batches_across_connections_on_two_handles(pkg, synth, worker):
         if p.poll() is None:
             p.kill()
             p.wait()
+
+
+def test_worker_decodes_a_voice_profile_file(pkg, synth, vo, worker, tmp_path):
+    """A voice JSON ([N,16] codec tokens + ref_text, src/voice_loader.rs:10-17) is the one realistic code source a
+    deployment has on disk: load it with the mirror loader, send it as one Vocode request, compare with the oracle."""
+    cfg = synth.SMALL
+    # reference-speaker-like statistics: codes dwell (repeat across frames) instead of being i.i.d. uniform
+    rng = np.random.default_rng(7)
+    base = synth.make_codes(23, 3, cfg)
+    hold = rng.random(base.shape) < 0.6
+    for t in range(1, base.shape[0]):
+        base[t] = np.where(hold[t], base[t - 1], base[t])
+    path = str(tmp_path / "speaker.json")
+    pkg.voice.save_voice_json(path, base, "reference sentence")
+    codes, text = pkg.voice.load_voice_file(path)
+    assert text == "reference sentence" and np.array_equal(codes, base)
+    c = pkg.wire.WorkerClient("127.0.0.1", worker)
+    pcm = c.vocode(codes)
+    ref = oracle_for(vo, synth, "SMALL", 0).synthesize(codes, 4)
+    assert pcm.size == ref.size
+    assert np.abs(pcm.astype(np.int32) - vo.pcm16(ref).astype(np.int32)).max() <= 33
