@@ -24,3 +24,10 @@ def load_oracle():
         sys.path.insert(0, ROOT)
     from oracle import voc_oracle
     return voc_oracle
+
+
+def load_enc_oracle():
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    from oracle import enc_oracle
+    return enc_oracle

@@ -203,3 +203,125 @@ def save_safetensors(path: str, tensors: Dict[str, np.ndarray], metadata: Dict[s
 
 def config_dict(cfg: DecoderConfig) -> dict:
     return asdict(cfg)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Speech-tokenizer ENCODER (/root/reference/src/speech_tokenizer.rs): seeded weights under the
+# tensor names its loader reads (178-232, 407-424, 482-533, 595-632), so a real speech_tokenizer/model.safetensors
+# loads through the same path.
+@dataclass(frozen=True)
+class EncoderConfig:
+    n_filters: int = 64                      # speech_tokenizer.rs:18
+    ratios: Tuple[int, ...] = (4, 5, 6, 8)   # encoder order = RATIOS reversed (19, 183)
+    dimension: int = 512                     # 17
+    compress: int = 2                        # 20
+    kernel_size: int = 7                     # 21
+    residual_kernel_size: int = 3            # 22
+    last_kernel_size: int = 3                # 23
+    num_layers: int = 8                      # 24
+    num_heads: int = 8                       # 25
+    dim_feedforward: int = 2048              # 26
+    context: int = 250                       # 27
+    rope_max_period: float = 10000.0         # 28
+    n_use_codebooks: int = 16                # 29
+    codebook_size: int = 2048                # 30
+    codebook_dim: int = 256                  # 31
+    n_semantic: int = 1                      # 32
+    n_acoustic: int = 31                     # 33
+    downsample_stride: int = 2               # 626-628
+
+    def n_frames(self, n_samples: int) -> int:
+        n = n_samples
+        for r in self.ratios:
+            n //= r
+        return n // self.downsample_stride
+
+    @property
+    def samples_per_frame(self) -> int:
+        n = self.downsample_stride
+        for r in self.ratios:
+            n *= r
+        return n
+
+    def metadata(self) -> Dict[str, str]:
+        return {"n_heads": str(self.num_heads), "context": str(self.context),
+                "n_use_codebooks": str(self.n_use_codebooks), "rope_max_period": repr(float(self.rope_max_period))}
+
+
+ENC_FULL = EncoderConfig()
+# same time structure (1920 samples per frame), narrow channels, more codebooks than are used, a window that binds
+ENC_SMALL = EncoderConfig(n_filters=8, dimension=64, num_layers=2, num_heads=2, dim_feedforward=96, context=5,
+                          codebook_size=64, codebook_dim=24, n_acoustic=17)
+# odd widths (channel counts that are not multiples of the kernel tiles), fewer codebooks than the cut
+ENC_ODD = EncoderConfig(n_filters=6, dimension=40, num_layers=1, num_heads=5, dim_feedforward=56, context=3,
+                        codebook_size=37, codebook_dim=20, n_acoustic=6, last_kernel_size=3)
+
+
+def make_encoder_weights(cfg: EncoderConfig = ENC_FULL, seed: int = 0) -> Dict[str, np.ndarray]:
+    rng = np.random.default_rng(seed + 7919)
+    W: Dict[str, np.ndarray] = {}
+
+    def normal(shape, std):
+        return (rng.standard_normal(shape, dtype=np.float32) * np.float32(std)).astype(np.float32)
+
+    def uniform(shape, lo, hi):
+        return rng.uniform(lo, hi, size=shape).astype(np.float32)
+
+    def conv(prefix, cout, cin, k, gain=1.0, bias=True):
+        W[prefix + ".weight"] = normal((cout, cin, k), gain * (cin * k) ** -0.5)
+        if bias:
+            W[prefix + ".bias"] = normal((cout,), 0.05)
+
+    e = "encoder.encoder.layers"
+    conv(f"{e}.0.conv", cfg.n_filters, 1, cfg.kernel_size, gain=3.0)
+    idx, c = 1, cfg.n_filters
+    for r in cfg.ratios:
+        hid = c // cfg.compress
+        conv(f"{e}.{idx}.block.1.conv", hid, c, cfg.residual_kernel_size, gain=1.4)
+        conv(f"{e}.{idx}.block.3.conv", c, hid, 1, gain=1.0)
+        conv(f"{e}.{idx + 2}.conv", 2 * c, c, 2 * r, gain=1.6)
+        idx += 3
+        c *= 2
+    conv(f"{e}.{idx + 1}.conv", cfg.dimension, c, cfg.last_kernel_size, gain=1.4)
+    D = cfg.dimension
+    for i in range(cfg.num_layers):
+        p = f"encoder.encoder_transformer.layers.{i}"
+        for n in ("input_layernorm", "post_attention_layernorm"):
+            W[f"{p}.{n}.weight"] = (1.0 + normal((D,), 0.1)).astype(np.float32)
+            W[f"{p}.{n}.bias"] = normal((D,), 0.05)
+        for n in ("q_proj", "k_proj"):
+            W[f"{p}.self_attn.{n}.weight"] = normal((D, D), 1.5 * D ** -0.5)
+        W[f"{p}.self_attn.v_proj.weight"] = normal((D, D), D ** -0.5)
+        W[f"{p}.self_attn.o_proj.weight"] = normal((D, D), D ** -0.5)
+        W[f"{p}.self_attn_layer_scale.scale"] = uniform((D,), 0.05, 0.4)
+        W[f"{p}.mlp.fc1.weight"] = normal((cfg.dim_feedforward, D), D ** -0.5)
+        W[f"{p}.mlp.fc2.weight"] = normal((D, cfg.dim_feedforward), cfg.dim_feedforward ** -0.5)
+        W[f"{p}.mlp_layer_scale.scale"] = uniform((D,), 0.05, 0.4)
+    # downsample conv: the reference loads an optional bias (56); Mimi's has none -- give it none
+    conv("encoder.downsample.conv", D, D, 2 * cfg.downsample_stride, bias=False)
+    for group, n in (("semantic", cfg.n_semantic), ("acoustic", cfg.n_acoustic)):
+        q = f"encoder.quantizer.{group}_residual_vector_quantizer"
+        W[f"{q}.input_proj.weight"] = normal((cfg.codebook_dim, D, 1), D ** -0.5)
+        W[f"{q}.output_proj.weight"] = normal((D, cfg.codebook_dim, 1), cfg.codebook_dim ** -0.5)
+        for i in range(n):
+            usage = uniform((cfg.codebook_size,), 0.5, 50.0)
+            # residual scale shrinks with depth, as in a trained RVQ
+            emb = normal((cfg.codebook_size, cfg.codebook_dim), 0.9 * 0.75 ** i)
+            W[f"{q}.layers.{i}.codebook.cluster_usage"] = usage
+            W[f"{q}.layers.{i}.codebook.embed_sum"] = (emb * usage[:, None]).astype(np.float32)
+    return W
+
+
+def make_audio(n_samples: int, seed: int) -> np.ndarray:
+    """Speech-like synthetic 24 kHz mono clip in (-1, 1): a few drifting harmonics under a syllable-rate envelope
+    plus a little noise (no real recordings exist offline)."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(n_samples, dtype=np.float64) / 24000.0
+    f0 = 110.0 + 40.0 * np.sin(2 * np.pi * 0.7 * t + rng.uniform(0, 6.28)) + rng.uniform(-20, 60)
+    phase = 2 * np.pi * np.cumsum(f0) / 24000.0
+    x = np.zeros(n_samples)
+    for h in range(1, 9):
+        x += rng.uniform(0.2, 1.0) / h * np.sin(h * phase + rng.uniform(0, 6.28))
+    env = 0.55 + 0.45 * np.sin(2 * np.pi * 3.1 * t + rng.uniform(0, 6.28))
+    x = x * env * 0.18 + 0.01 * rng.standard_normal(n_samples)
+    return np.clip(x, -0.99, 0.99).astype(np.float32)

@@ -32,6 +32,11 @@ def vo():
     return _pkgload.load_oracle()
 
 
+@pytest.fixture(scope="session")
+def eo():
+    return _pkgload.load_enc_oracle()
+
+
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"))
 
@@ -65,3 +70,23 @@ def snr_db(ref, x):
     if den == 0:
         return float("inf")
     return 10.0 * np.log10(num / den)
+
+
+_EW_CACHE = {}
+_EO_CACHE = {}
+
+
+def enc_weights_for(synth, cfg_name, seed):
+    key = (cfg_name, int(seed))
+    if key not in _EW_CACHE:
+        _EW_CACHE[key] = synth.make_encoder_weights(getattr(synth, cfg_name), int(seed))
+    return _EW_CACHE[key]
+
+
+def enc_oracle_for(eo, synth, cfg_name, seed):
+    key = (cfg_name, int(seed))
+    if key not in _EO_CACHE:
+        cfg = getattr(synth, cfg_name)
+        _EO_CACHE[key] = eo.EncOracle(enc_weights_for(synth, cfg_name, seed),
+                                      {k: float(v) for k, v in cfg.metadata().items()})
+    return _EO_CACHE[key]
