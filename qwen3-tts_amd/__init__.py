@@ -7,4 +7,6 @@ from . import sharding, synth  # noqa: F401
 from . import hipvoc  # noqa: F401
 from . import wire  # noqa: F401
 from . import voice  # noqa: F401
+from . import encoder  # noqa: F401
+from .encoder import HipSpeechTokenizer  # noqa: F401
 from .hipvoc import HipVocoder, HipVocError, lib_path, load_library  # noqa: F401

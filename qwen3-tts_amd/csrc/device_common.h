@@ -73,6 +73,11 @@ __device__ __forceinline__ float snake_beta(float x, float ea, float ib) {
 }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// encoder path: ELU(alpha = 1) as speech_tokenizer.rs:84-92 writes it, and candle's tanh-form GELU (:438)
+__device__ __forceinline__ float elu1(float v) { return fmaxf(v, 0.0f) + (expf(fminf(v, 0.0f)) - 1.0f); }
+__device__ __forceinline__ float gelu_tanh(float v) {
+    return 0.5f * v * (1.0f + tanhf(0.7978845608028654f * v * (1.0f + 0.044715f * v * v)));
+}
 
 
 // Per-row parameter table in LDS, filled once at kernel start and read by the epilogues (and, in the fused
@@ -117,7 +122,7 @@ __device__ __forceinline__ uint2 pack4_bf16(float a, float b, float c, float d) 
 // as bf16 in channel-group-major form.  For S == 1 a lane's four rows (r&3) are half of a channel group: one 8-byte
 // store; the same holds for transposed convs with phase-major rows (ConvGemmArgs::pm); with channel-major rows
 // (channel, phase) pairs the bf16 values go out one by one.
-template <int BN>
+template <int BN, bool ENC = false>
 __device__ __forceinline__ void conv_epilogue_tile(const ConvGemmArgs &a, const f32x16 &acc, const float *Pm, int n0, int rbase,
                                                    int m, float *yu, const float *ru, float *y2u, unsigned short *ybu = nullptr) {
 #pragma unroll
@@ -173,6 +178,15 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvGemmArgs &a, const 
         if (a.act == ACT_CLAMP1) {
 #pragma unroll
             for (int q = 0; q < 8; q++) v[q] = fminf(fmaxf(v[q], -1.0f), 1.0f);
+        }
+        if constexpr (ENC) {
+            if (a.act == ACT_ELU) {
+#pragma unroll
+                for (int q = 0; q < 8; q++) v[q] = elu1(v[q]);
+            } else if (a.act == ACT_GELU_TANH) {
+#pragma unroll
+                for (int q = 0; q < 8; q++) v[q] = gelu_tanh(v[q]);
+            }
         }
         if (ybu) {
             float w[8];

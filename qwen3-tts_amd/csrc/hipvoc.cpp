@@ -8,6 +8,7 @@
 //   hipvoc_vocode_pcm16  <- Worker::handle_vocode        src/worker/mod.rs:507-531
 // The decoder graph itself (inside the reference's opaque vocoder.onnx) follows SURVEY.md 8a g1-g7.
 #include "../../include/hipvoc.h"
+#include "../../include/hipvoc_encoder.h"
 
 #include <hip/hip_runtime.h>
 
@@ -88,6 +89,7 @@ struct Step {
 struct Plan {
     int G = 0, T = 0;
     std::vector<Step> steps;
+    float *enc_audio = nullptr;    // encoder plans: the input buffer this plan's first step reads
 };
 
 struct Ctx {
@@ -99,6 +101,7 @@ struct Ctx {
     bool post_snake = true;
     bool phase_major = true;   // bf16 mode: transposed-conv rows phase-major (HIPVOC_PHASE_MAJOR=0: channel-major)
     bool packed = true;        // bf16 mode: GEMM-to-GEMM tensors of the decoder stack exchanged as packed bf16 (HIPVOC_PACKED=0: fp32)
+    bool is_encoder = false;   // handle made by hipvoc_enc_load (encoder.inc.cpp): the vocoder entry points refuse it
     bool bf16 = false;         // HIPVOC_DTYPE_BF16: conv-GEMM operands in bf16, fp32 accumulate, everything else fp32
     int dual_out = 1;          // un-fused residual units, SnakeBeta in the producer's epilogue: 0 never, 1 conv7 -> conv1 only
                                // (no extra write), 2 also x / snake(x) written side by side (HIPVOC_DUAL)
@@ -575,8 +578,9 @@ struct PlanBuilder {
     // x[Cin][G][Lpi] -> y[N/S][G][Lpo]
     void gemm(const char *name, const Gemm &g, const float *x, int Lin, int Lpi, float *y, int Lpo, const Snake *sn,
               const float *res, const float *rscale, int act, const Snake *post = nullptr, float *y2 = nullptr,
-              const unsigned short *xb = nullptr, unsigned short *yb = nullptr) {
+              const unsigned short *xb = nullptr, unsigned short *yb = nullptr, int in_elu = 0) {
         ConvGemmArgs a{};
+        a.in_elu = in_elu;
         a.x = x; a.y = y; a.w = g.w; a.wb = g.wb; a.bias = g.bias; a.res = res; a.rscale = rscale; a.y2 = post ? y2 : nullptr;
         a.xb = xb; a.yb = yb;
         a.psn_a = post ? post->ea : nullptr; a.psn_ib = post ? post->ib : nullptr;
@@ -664,7 +668,7 @@ static Plan *get_plan(Ctx *c, int G, int T, bool debug = false) {
             b.gemm("qkv", ly.qkv, xn, T, Tp, qkv, Tp, nullptr, nullptr, nullptr, ACT_NONE);
             int nh = c->n_heads, hd = c->head_dim, win = c->window;
             const float *ct = c->cos_t, *sn = c->sin_t;
-            b.add("attention", "attention_kernel", (double)G * nh * T * T * hd, [=](hipStream_t s) {
+            b.add("attention", "attention_kernel<32>", (double)G * nh * T * T * hd, [=](hipStream_t s) {
                 return launch_attention(qkv, ao, ct, sn, nh, hd, G, T, Tp, win, s);
             });
             b.gemm("o_proj", ly.o, ao, T, Tp, h, Tp, nullptr, h, ly.ls1, ACT_NONE);
@@ -1007,6 +1011,8 @@ static int build_units(Ctx *c, const int64_t *codes, const int32_t *n_frames, in
     return HIPVOC_OK;
 }
 
+static void enc_release(Ctx *c);      // encoder.inc.cpp
+
 }  // namespace hipvoc
 
 // =================================================================================================
@@ -1062,6 +1068,10 @@ void *hipvoc_load(const char *weights_path, int device_id, int dtype, int unit_f
     Ctx *c = (Ctx *)(h);          \
     if (!c) return HIPVOC_E_ARG;  \
     if (hipSetDevice(c->device) != hipSuccess) { c->err = "hipSetDevice failed"; return HIPVOC_E_HIP; }
+// vocoder entry points: not on an encoder handle
+#define DEC(h)                    \
+    CTX(h)                        \
+    if (c->is_encoder) { c->err = "this handle is an encoder (hipvoc_enc_load)"; return HIPVOC_E_ARG; }
 
 int hipvoc_max_tokens(void *h) { return h ? ((Ctx *)h)->unit_frames : HIPVOC_E_ARG; }
 int64_t hipvoc_unit_samples(void *h) { return h ? ((Ctx *)h)->out_len(((Ctx *)h)->unit_frames) : HIPVOC_E_ARG; }
@@ -1070,14 +1080,14 @@ int64_t hipvoc_unit_macs(void *h) { return h ? ((Ctx *)h)->unit_macs : HIPVOC_E_
 void *hipvoc_stream(void *h) { return h ? (void *)((Ctx *)h)->stream : nullptr; }
 
 int hipvoc_decode_units_device(void *h, const int64_t *d_codes, int n_units, float *d_out, size_t unit_stride) {
-    CTX(h);
+    DEC(h);
     if (!d_codes || !d_out || n_units < 0) { c->err = "bad argument"; return HIPVOC_E_ARG; }
     if ((int64_t)unit_stride < c->out_len(c->unit_frames)) { c->err = "unit_stride smaller than unit_samples"; return HIPVOC_E_CAP; }
     return decode_units_device(c, (const long long *)d_codes, n_units, d_out, unit_stride);
 }
 
 int hipvoc_sync(void *h) {
-    CTX(h);
+    DEC(h);
     return sync_check(c);
 }
 
@@ -1129,7 +1139,7 @@ static int decode_host(Ctx *c, const int64_t *codes, const int32_t *n_frames, in
 }
 
 int hipvoc_run(void *h, const int64_t *codes, int max_tokens, float *out, size_t out_cap, size_t *n_out) {
-    CTX(h);
+    DEC(h);
     if (!codes || !out) { c->err = "null pointer"; return HIPVOC_E_ARG; }
     if (max_tokens != c->unit_frames) { c->err = "hipvoc_run: max_tokens must equal the handle's unit_frames"; return HIPVOC_E_ARG; }
     int64_t Lu = c->out_len(c->unit_frames);
@@ -1154,7 +1164,7 @@ int hipvoc_run(void *h, const int64_t *codes, int max_tokens, float *out, size_t
 }
 
 int hipvoc_decode(void *h, const int64_t *codes, int n_frames, float *out, size_t out_cap, size_t *n_out) {
-    CTX(h);
+    DEC(h);
     if ((!codes && n_frames > 0) || (!out && n_frames > 0) || n_frames < 0) { c->err = "bad argument"; return HIPVOC_E_ARG; }
     int32_t nf = n_frames;
     size_t off = 0, n = 0;
@@ -1165,7 +1175,7 @@ int hipvoc_decode(void *h, const int64_t *codes, int n_frames, float *out, size_
 
 int hipvoc_decode_batch(void *h, const int64_t *codes, const int32_t *n_frames, int B, float *out, const size_t *out_off,
                         size_t *n_out) {
-    CTX(h);
+    DEC(h);
     if (B < 0 || (B > 0 && (!codes || !n_frames || !out || !out_off || !n_out))) { c->err = "bad argument"; return HIPVOC_E_ARG; }
     std::vector<size_t> cap(B);
     for (int b = 0; b < B; b++) cap[b] = (size_t)std::max(n_frames[b], 0) * HIPVOC_SAMPLES_PER_TOKEN;
@@ -1173,7 +1183,7 @@ int hipvoc_decode_batch(void *h, const int64_t *codes, const int32_t *n_frames, 
 }
 
 int hipvoc_vocode_pcm16(void *h, const uint8_t *codes_le, int n_frames, int16_t *pcm, size_t pcm_cap, size_t *n_samples) {
-    CTX(h);
+    DEC(h);
     if (n_frames < 0 || (n_frames > 0 && (!codes_le || !pcm))) { c->err = "bad argument"; return HIPVOC_E_ARG; }
     size_t n = (size_t)n_frames * c->n_q;
     std::vector<int64_t> codes(n);
@@ -1196,7 +1206,7 @@ int hipvoc_num_stages(void *h) {
 }
 
 int hipvoc_debug_stage(void *h, const int64_t *codes, int n_frames, int stage, float *out, size_t out_cap, int *Cc, int64_t *Ll) {
-    CTX(h);
+    DEC(h);
     if (!codes || !out || n_frames < 1 || n_frames > c->unit_frames) { c->err = "bad argument"; return HIPVOC_E_ARG; }
     int nst = hipvoc_num_stages(h);
     if (!((stage >= 0 && stage < nst) || stage == 1000)) { c->err = "no such stage"; return HIPVOC_E_STAGE; }
@@ -1265,7 +1275,10 @@ void hipvoc_free(void *h) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
+    enc_release(c);
     delete c;
 }
 
 }  // extern "C"
+
+#include "encoder.inc.cpp"

@@ -10,7 +10,9 @@
 
 namespace hipvoc {
 
-enum Act { ACT_NONE = 0, ACT_GELU = 1, ACT_CLAMP1 = 2 };
+enum Act { ACT_NONE = 0, ACT_GELU = 1, ACT_CLAMP1 = 2,
+           // encoder path only (fp32 kernel, ENC variant): applied AFTER the residual add
+           ACT_ELU = 3, ACT_GELU_TANH = 4 };
 
 // Implicit-GEMM convolution family:  y[n][m] = epi( sum_tap sum_ci W[tap][ci][n] * pro(x[ci][m + shift(tap)]) )
 // rows n = output channel (x S output phases for transposed convs), columns m = time positions.
@@ -55,6 +57,7 @@ struct ConvGemmArgs {
     int Lin;                         // valid input positions per unit
     long x_us, x_cs, y_us, y_cs;     // unit / channel strides in floats
     int act;
+    int in_elu;                      // encoder path (fp32 kernel, ENC variant): ELU(alpha=1) on the input in the staging loop
     int dbg;                         // timing-only ablation bits (set by the launcher from HIPVOC_DBG; 0 in production)
 };
 hipError_t launch_conv_gemm(const ConvGemmArgs &a, hipStream_t s);
@@ -101,5 +104,23 @@ hipError_t launch_final_conv(const float *x, float *out, const float *w, const f
 
 // f32 -> i16 PCM: (s*32767.0).clamp(-32768.0, 32767.0) as i16   (src/worker/mod.rs:521-524)
 hipError_t launch_pcm16(const float *x, int16_t *y, long n, hipStream_t s);
+
+// ---- speech-tokenizer encoder (kernels_enc.hip; /root/reference/src/speech_tokenizer.rs) -------------------------
+// y[(c*r + j)][u][q] = act(x[c][u][q*r + j]) for q < L / r: the space-to-depth form in which a conv of kernel 2r and
+// stride r (CausalConv1d with pad k - s = r) is a 2-tap conv over c*r channels.  elu: apply ELU(alpha=1) first.
+hipError_t launch_s2d(const float *x, float *y, int C, int G, int L, int Lp, int r, int Lq, int Lqp, int elu, hipStream_t s);
+// LayerNorm with bias over channels of x[C][P] (speech_tokenizer.rs:394-403): biased variance, eps inside the sqrt
+hipError_t launch_layernorm(const float *x, float *y, const float *w, const float *b, int C, long P, float eps, hipStream_t s);
+struct RvqEncArgs {
+    const float *h;        // latent [dim][G][Lp]
+    const float *wp_t;     // [2][dim][D]: transposed input_proj of the semantic, then the acoustic quantiser
+    const float *emb_t;    // [nq][D][cb_size]: codebooks, transposed (layer 0.. = semantic layers, then acoustic)
+    const float *e_sq;     // [nq][cb_size]
+    long long *codes;      // [G][T][nq]
+    float *proj;           // optional [2*D][G][Lp]: the projected latents (debug) or null
+    int dim, D, cb_size, n_sem, n_ac, T, Lp, G;
+};
+// Nearest-codeword search, bit-exact contract of oracle/enc_oracle.c (k-ascending fmaf chains, first minimum)
+hipError_t launch_rvq_encode(const RvqEncArgs &a, hipStream_t s);
 
 }  // namespace hipvoc

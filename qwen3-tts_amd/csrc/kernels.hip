@@ -43,7 +43,8 @@ static constexpr int BK = 16;    // input channels per K stage
 //    2-tap transposed convs; weights straight from L2 instead of LDS were 15% slower.)
 // -------------------------------------------------------------------------------------------------
 
-template <int TN, bool FUSE, int NW>
+// ENC: the encoder path's variant (ELU on the input, ELU / tanh-GELU epilogues); compiled out of the vocoder's kernels
+template <int TN, bool FUSE, int NW, bool ENC = false>
 __global__ __launch_bounds__(NW * 64, (FUSE && TN > 4) ? 2 : 4) void conv_gemm_kernel(ConvGemmArgs a, int HL, int XW, int tiles_per_unit,
                                                                            int n_tiles) {
     constexpr int NTH = NW * 64;                     // NW waves; the workgroup covers BM = 32*NW positions
@@ -171,6 +172,9 @@ __global__ __launch_bounds__(NW * 64, (FUSE && TN > 4) ? 2 : 4) void conv_gemm_k
             f32x2 lo = snake_beta2(mk2(v.x, v.y), (f32x2)(sp.x), (f32x2)(sp.y));
             f32x2 hi = snake_beta2(mk2(v.z, v.w), (f32x2)(sp.x), (f32x2)(sp.y));
             v = make_float4(lo.x, lo.y, hi.x, hi.y);
+        }
+        if constexpr (ENC) {
+            if (a.in_elu) v = make_float4(elu1(v.x), elu1(v.y), elu1(v.z), elu1(v.w));   // elu(0) == 0 keeps the padding
         }
         *reinterpret_cast<float4 *>(smem + buf * xtile + k * XW + c4 * 4) = v;
     };
@@ -328,7 +332,7 @@ __global__ __launch_bounds__(NW * 64, (FUSE && TN > 4) ? 2 : 4) void conv_gemm_k
     float *y2u = y2u0 ? y2u0 + (long)unit * a.y_us : nullptr;
     const int m = m0 + wave * 32 + l31;
 #pragma unroll
-    for (int i = 0; i < TN; i++) conv_epilogue_tile<BN>(a, acc[i], Pm, n0, i * 32 + 4 * h, m, yu, ru, y2u);
+    for (int i = 0; i < TN; i++) conv_epilogue_tile<BN, ENC>(a, acc[i], Pm, n0, i * 32 + 4 * h, m, yu, ru, y2u);
 }
 #undef W_LOAD_FROM
 #undef W_LOAD
@@ -372,11 +376,12 @@ using detail::conv_gemm_launch_tn;
 
 const char *conv_gemm_kernel_name(const ConvGemmArgs &a) {
     if (a.wb) return conv_gemm_bf16_kernel_name(a);
-    static char names[2][2][8][40];
+    static char names[3][2][8][48];
     int tn = conv_gemm_launch_tn(a);
     int fuse = a.w2 ? 1 : 0, nw = conv_gemm_waves(a);
-    char *n = names[fuse][nw == 4][tn & 7];
-    if (!n[0]) snprintf(n, 40, "conv_gemm_kernel<%d,%s,%d>", tn, fuse ? "true" : "false", nw);
+    const bool enc = a.in_elu || a.act == ACT_ELU || a.act == ACT_GELU_TANH;
+    char *n = names[enc ? 2 : fuse][nw == 4][tn & 7];
+    if (!n[0]) snprintf(n, 48, enc ? "conv_gemm_kernel<%d,%s,%d,true>" : "conv_gemm_kernel<%d,%s,%d>", tn, fuse ? "true" : "false", nw);
     return n;
 }
 
@@ -390,7 +395,7 @@ size_t conv_gemm_lds_bytes(const ConvGemmArgs &a) {
     return sizeof(float) * fl;
 }
 
-template <int TN, bool FUSE, int NW>
+template <int TN, bool FUSE, int NW, bool ENC = false>
 static hipError_t conv_gemm_launch_one(const ConvGemmArgs &a, int HL, int XW, int tiles_per_unit, int n_tiles,
                                        long grid, size_t lds, hipStream_t s) {
     static bool done[64] = {};
@@ -398,12 +403,12 @@ static hipError_t conv_gemm_launch_one(const ConvGemmArgs &a, int HL, int XW, in
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 64 && !done[dev]) {   // dynamic LDS above 64 KiB must be enabled per function and device
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_gemm_kernel<TN, FUSE, NW>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_gemm_kernel<TN, FUSE, NW, ENC>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         done[dev] = true;
     }
-    hipLaunchKernelGGL((conv_gemm_kernel<TN, FUSE, NW>), dim3((unsigned)grid), dim3(NW * 64), lds, s, a, HL, XW, tiles_per_unit,
+    hipLaunchKernelGGL((conv_gemm_kernel<TN, FUSE, NW, ENC>), dim3((unsigned)grid), dim3(NW * 64), lds, s, a, HL, XW, tiles_per_unit,
                        n_tiles);
     return hipGetLastError();
 }
@@ -427,6 +432,7 @@ hipError_t launch_conv_gemm(const ConvGemmArgs &a_in, hipStream_t s) {
         return hipErrorInvalidValue;
     const int tn = conv_gemm_launch_tn(a);
     if (a.y2 && (!a.psn_a || !a.psn_ib || a.w2)) return hipErrorInvalidValue;
+    if ((a.in_elu || a.act == ACT_ELU || a.act == ACT_GELU_TANH) && (a.w2 || a.sn_a)) return hipErrorInvalidValue;
     if (a.w2 && (a.S != 1 || a.NP != 32 * tn || (a.N + 31) / 32 != tn || tn == 5 || tn > 6 || !a.res || !a.sn2_a ||
                  !a.sn2_ib || !a.bias || !a.bias2 || ((uintptr_t)a.w2 & 15)))
         return hipErrorInvalidValue;
@@ -455,6 +461,16 @@ hipError_t launch_conv_gemm(const ConvGemmArgs &a_in, hipStream_t s) {
             case 4: GO(4, true);
             default: GO(6, true);
         }
+    }
+    if (a.in_elu || a.act == ACT_ELU || a.act == ACT_GELU_TANH) {
+#define GOE(TN_) return conv_gemm_launch_one<TN_, false, 8, true>(a, HL, XW, tiles_per_unit, n_tiles, grid, lds, s)
+        switch (tn) {
+            case 1: GOE(1);
+            case 2: GOE(2);
+            case 3: GOE(3);
+            default: GOE(4);
+        }
+#undef GOE
     }
     switch (tn) {
         case 1: GO(1, false);
@@ -545,8 +561,9 @@ hipError_t launch_rmsnorm(const float *x, float *y, const float *w, int C, long 
 // Attention: one workgroup per (unit, head, block of 32 queries).  RoPE (rotate-half) is applied
 // while q and k are staged into LDS.  Mask: kv <= q && kv > q - window.  fp32 softmax.
 // -------------------------------------------------------------------------------------------------
-static constexpr int QB = 32;
-
+// QB queries per workgroup, 256 / QB threads per query row (QB = 32 for the vocoder's window of 72; the encoder's
+// window of 250 needs QB = 16 to fit K, V and the score rows into LDS)
+template <int QB>
 __global__ __launch_bounds__(256) void attention_kernel(const float *qkv, float *out, const float *cos_t,
                                                          const float *sin_t, int nh, int hd, int G, int T, int Lp,
                                                          int window, int NKP) {
@@ -593,13 +610,14 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *qkv, float 
         Vs[d * NKP + tk] = vp[(long)d * cs + k_lo + tk];
     }
     __syncthreads();
-    // scores + softmax: 8 threads per query row
-    int tq = tid >> 3, l8 = tid & 7;
+    // scores + softmax: TPR threads per query row
+    constexpr int TPR = 256 / QB;
+    int tq = tid / TPR, l8 = tid % TPR;
     float scaling = 1.0f / sqrtf((float)hd);
     int t_abs = q0 + tq;
     float mx = -INFINITY;
     if (tq < nq) {
-        for (int tk = l8; tk < nk; tk += 8) {
+        for (int tk = l8; tk < nk; tk += TPR) {
             int kt = k_lo + tk;
             bool ok = kt <= t_abs && kt > t_abs - window;
             float sc = -INFINITY;
@@ -612,25 +630,23 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *qkv, float 
             mx = fmaxf(mx, sc);
         }
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 1));
-    mx = fmaxf(mx, __shfl_xor(mx, 2));
-    mx = fmaxf(mx, __shfl_xor(mx, 4));
+#pragma unroll
+    for (int sh = 1; sh < TPR; sh <<= 1) mx = fmaxf(mx, __shfl_xor(mx, sh));
     float den = 0.0f;
     if (tq < nq) {
-        for (int tk = l8; tk < nk; tk += 8) {
+        for (int tk = l8; tk < nk; tk += TPR) {
             float sc = Ps[tq * NKP + tk];
             float e = sc == -INFINITY ? 0.0f : expf(sc - mx);
             Ps[tq * NKP + tk] = e;
             den += e;
         }
     }
-    den += __shfl_xor(den, 1);
-    den += __shfl_xor(den, 2);
-    den += __shfl_xor(den, 4);
+#pragma unroll
+    for (int sh = 1; sh < TPR; sh <<= 1) den += __shfl_xor(den, sh);
     __syncthreads();
     if (tq < nq) {
         float inv = 1.0f / den;
-        for (int d = l8; d < hd; d += 8) {
+        for (int d = l8; d < hd; d += TPR) {
             float acc = 0.0f;
             for (int tk = 0; tk < nk; tk++) acc += (Ps[tq * NKP + tk] * inv) * Vs[d * NKP + tk];
             out[(long)(hh * hd + d) * cs + base + t_abs] = acc;
@@ -641,18 +657,30 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *qkv, float 
 hipError_t launch_attention(const float *qkv, float *out, const float *cos_t, const float *sin_t, int nh, int hd,
                             int G, int T, int Lp, int window, hipStream_t s) {
     if (G <= 0) return hipSuccess;
-    int nkmax = QB + (window > 1 ? window - 1 : 0);
-    if (nkmax > T) nkmax = T;
-    int NKP = nkmax | 1;    // odd stride: conflict-free column walks
-    size_t lds = sizeof(float) * ((size_t)hd * QB + 2 * (size_t)hd * NKP + (size_t)QB * NKP);
-    if (lds > 160 * 1024 || (hd & 1)) return hipErrorInvalidValue;
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attention_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
+    if (hd & 1) return hipErrorInvalidValue;
+    for (int qb = 32; qb >= 8; qb >>= 1) {
+        int nkmax = qb + (window > 1 ? window - 1 : 0);
+        if (nkmax > T) nkmax = T;
+        int NKP = nkmax | 1;    // odd stride: conflict-free column walks
+        size_t lds = sizeof(float) * ((size_t)hd * qb + 2 * (size_t)hd * NKP + (size_t)qb * NKP);
+        if (lds > 160 * 1024) continue;
+        dim3 g(G, nh, (T + qb - 1) / qb);
+#define ATT_GO(QB_)                                                                                                  \
+        {                                                                                                            \
+            if (lds > 64 * 1024) {                                                                                   \
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attention_kernel<QB_>),            \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);          \
+                if (e != hipSuccess) return e;                                                                       \
+            }                                                                                                        \
+            hipLaunchKernelGGL(attention_kernel<QB_>, g, dim3(256), lds, s, qkv, out, cos_t, sin_t, nh, hd, G, T, Lp, window, NKP); \
+            return hipGetLastError();                                                                                \
+        }
+        if (qb == 32) ATT_GO(32)
+        if (qb == 16) ATT_GO(16)
+        ATT_GO(8)
+#undef ATT_GO
     }
-    dim3 g(G, nh, (T + QB - 1) / QB);
-    hipLaunchKernelGGL(attention_kernel, g, dim3(256), lds, s, qkv, out, cos_t, sin_t, nh, hd, G, T, Lp, window, NKP);
-    return hipGetLastError();
+    return hipErrorInvalidValue;
 }
 
 // -------------------------------------------------------------------------------------------------

@@ -1,0 +1,159 @@
+"""ctypes binding of the encoder entry points of libhipvoc.so (include/hipvoc_encoder.h).
+
+Host-side mirror of the reference's SpeechTokenizer (src/speech_tokenizer.rs:608-741): ``HipSpeechTokenizer.load(path)``,
+``.encode(audio) -> [n_tokens, 16] int64``, ``resample(samples, from_rate, to_rate)``; ``encode_samples`` does what
+``encode_wav`` does after the file is read (mono mix, resample to 24 kHz; speech_tokenizer.rs:698-720).
+
+There is NO fallback: if the shared library is missing or no HIP device is present, loading raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Sequence
+
+import numpy as np
+
+from .hipvoc import HipVocError, load_library
+
+SAMPLE_RATE = 24000             # speech_tokenizer.rs:15
+
+ENC_EXPORTS = [
+    "hipvoc_enc_load", "hipvoc_enc_n_codebooks", "hipvoc_enc_samples_per_frame", "hipvoc_enc_n_frames",
+    "hipvoc_enc_macs_per_sample", "hipvoc_enc_encode", "hipvoc_enc_encode_batch", "hipvoc_enc_num_stages",
+    "hipvoc_enc_debug_stage", "hipvoc_resample_linear",
+]
+
+_bound = False
+
+
+def _lib():
+    global _bound
+    L = load_library()
+    if not _bound:
+        vp, sz = C.c_void_p, C.c_size_t
+        L.hipvoc_enc_load.restype = vp
+        L.hipvoc_enc_load.argtypes = [C.c_char_p, C.c_int]
+        L.hipvoc_enc_n_codebooks.argtypes = [vp]
+        L.hipvoc_enc_samples_per_frame.argtypes = [vp]
+        L.hipvoc_enc_n_frames.restype = C.c_int64
+        L.hipvoc_enc_n_frames.argtypes = [vp, C.c_int64]
+        L.hipvoc_enc_macs_per_sample.restype = C.c_double
+        L.hipvoc_enc_macs_per_sample.argtypes = [vp]
+        L.hipvoc_enc_encode.argtypes = [vp, vp, C.c_int64, vp, sz, C.POINTER(C.c_int64)]
+        L.hipvoc_enc_encode_batch.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp]
+        L.hipvoc_enc_num_stages.argtypes = [vp]
+        L.hipvoc_enc_debug_stage.argtypes = [vp, vp, C.c_int64, C.c_int, vp, sz, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
+        L.hipvoc_resample_linear.restype = C.c_int64
+        L.hipvoc_resample_linear.argtypes = [vp, C.c_int64, C.c_uint32, C.c_uint32, vp, C.c_int64]
+        _bound = True
+    return L
+
+
+def resample(samples, from_rate: int, to_rate: int) -> np.ndarray:
+    """Linear resampling as the reference does it (speech_tokenizer.rs:725-741)."""
+    x = np.ascontiguousarray(samples, dtype=np.float32).reshape(-1)
+    L = _lib()
+    n = int(L.hipvoc_resample_linear(x.ctypes.data, x.size, from_rate, to_rate, None, 0))
+    if n < 0:
+        raise HipVocError(n, "resample: bad argument")
+    out = np.empty(n, dtype=np.float32)
+    L.hipvoc_resample_linear(x.ctypes.data, x.size, from_rate, to_rate, out.ctypes.data, out.size)
+    return out
+
+
+class HipSpeechTokenizer:
+    """SpeechTokenizer: 24 kHz mono waveform -> codec tokens on one MI355X (speech_tokenizer.rs:608-675)."""
+
+    def __init__(self, handle, lib):
+        self._h = handle
+        self._L = lib
+        self.n_codebooks = int(lib.hipvoc_enc_n_codebooks(handle))
+        self.samples_per_frame = int(lib.hipvoc_enc_samples_per_frame(handle))
+        self.macs_per_sample = float(lib.hipvoc_enc_macs_per_sample(handle))
+
+    @classmethod
+    def load(cls, model_path: str, device: int = 0) -> "HipSpeechTokenizer":
+        L = _lib()
+        h = L.hipvoc_enc_load(os.fsencode(model_path), device)
+        if not h:
+            raise HipVocError(-6, L.hipvoc_last_error(None).decode())
+        return cls(h, L)
+
+    def close(self):
+        if self._h:
+            self._L.hipvoc_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise HipVocError(rc, self._L.hipvoc_last_error(self._h).decode())
+
+    def n_frames(self, n_samples: int) -> int:
+        return int(self._L.hipvoc_enc_n_frames(self._h, n_samples))
+
+    def encode(self, audio) -> np.ndarray:
+        """audio: 24 kHz mono f32 -> codes [n_tokens, n_codebooks] int64 (SpeechTokenizer::encode, 646-675)."""
+        a = np.ascontiguousarray(audio, dtype=np.float32).reshape(-1)
+        T = max(self.n_frames(a.size), 1)
+        out = np.empty((T, self.n_codebooks), dtype=np.int64)
+        n = C.c_int64(0)
+        self._check(self._L.hipvoc_enc_encode(self._h, a.ctypes.data, a.size, out.ctypes.data, out.size, C.byref(n)))
+        return out[: n.value]
+
+    def encode_batch(self, clips: Sequence[np.ndarray]) -> List[np.ndarray]:
+        """Several clips in one pass; each result equals encode() of that clip alone, bit for bit."""
+        arrs = [np.ascontiguousarray(a, dtype=np.float32).reshape(-1) for a in clips]
+        B = len(arrs)
+        if B == 0:
+            return []
+        outs = [np.empty((max(self.n_frames(a.size), 1), self.n_codebooks), dtype=np.int64) for a in arrs]
+        ap = (C.c_void_p * B)(*[a.ctypes.data for a in arrs])
+        ns = (C.c_int64 * B)(*[a.size for a in arrs])
+        cp = (C.c_void_p * B)(*[o.ctypes.data for o in outs])
+        caps = (C.c_size_t * B)(*[o.size for o in outs])
+        nf = (C.c_int64 * B)()
+        self._check(self._L.hipvoc_enc_encode_batch(self._h, ap, ns, B, cp, caps, nf))
+        return [o[: nf[i]] for i, o in enumerate(outs)]
+
+    def encode_samples(self, samples, sample_rate: int, channels: int = 1) -> np.ndarray:
+        """What encode_wav does once the file is decoded (698-720): interleaved channels are averaged to mono, other
+        rates are resampled linearly to 24 kHz."""
+        x = np.ascontiguousarray(samples, dtype=np.float32).reshape(-1)
+        if channels > 1:
+            x = x[: x.size // channels * channels].reshape(-1, channels)
+            x = (x.sum(axis=1, dtype=np.float32) / np.float32(channels)).astype(np.float32)
+        if sample_rate != SAMPLE_RATE:
+            x = resample(x, sample_rate, SAMPLE_RATE)
+        return self.encode(x)
+
+    # ---- parity hooks ----------------------------------------------------------------------
+    @property
+    def n_stages(self) -> int:
+        return int(self._L.hipvoc_enc_num_stages(self._h))
+
+    def stage(self, audio, stage: int) -> np.ndarray:
+        a = np.ascontiguousarray(audio, dtype=np.float32).reshape(-1)
+        out = np.empty(max(a.size * 64, 1 << 16), dtype=np.float32)
+        c, l = C.c_int(0), C.c_int64(0)
+        self._check(self._L.hipvoc_enc_debug_stage(self._h, a.ctypes.data, a.size, stage, out.ctypes.data, out.size,
+                                                   C.byref(c), C.byref(l)))
+        return out[: c.value * l.value].reshape(c.value, l.value).copy()
+
+    def set_profile(self, on: bool):
+        self._check(self._L.hipvoc_set_profile(self._h, 1 if on else 0))
+
+    def last_profile(self):
+        cap = 128
+        names = (C.c_char_p * cap)()
+        ms = (C.c_float * cap)()
+        fl = (C.c_double * cap)()
+        ln = (C.c_int * cap)()
+        n = self._L.hipvoc_last_profile(self._h, names, ms, fl, ln, cap)
+        return {names[i].decode(): (float(ms[i]), float(fl[i]), int(ln[i])) for i in range(min(n, cap))}

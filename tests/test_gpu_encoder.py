@@ -1,0 +1,185 @@
+"""GPU parity tests of the speech-tokenizer ENCODER path through the C ABI
+(include/hipvoc_encoder.h) against oracle/enc_oracle.c.
+
+Bars:
+  * floating-point stages (SEANet convs, transformer, downsample, input projections): max-abs error <= 1e-3 of the
+    stage's peak and SNR >= 60 dB against the fp32 oracle, the vocoder path's fp32 gates;
+  * the integer part -- nearest-codeword search -- is BIT-EXACT: the oracle's quantiser applied to the GPU's own
+    latent must give exactly the GPU's codes (same distance expression, k-ascending fmaf chains, first minimum);
+  * end to end against the oracle's codes: a code can only differ where the two candidates' distances are within
+    round-off of each other (a near-tie flipped by the 1e-6 differences upstream); every differing frame is checked
+    for that, and the agreement rate is stated.
+"""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+from conftest import enc_oracle_for, enc_weights_for, load_golden, snr_db
+
+pytestmark = pytest.mark.gpu
+
+_ENC = {}
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _torch_hip_first():
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.init()
+    yield
+
+
+def enc_for(pkg, synth, cfg_name):
+    if cfg_name not in _ENC:
+        cfg = getattr(synth, cfg_name)
+        path = os.path.join(tempfile.gettempdir(), f"hipenc_test_{cfg_name}_0.safetensors")
+        synth.save_safetensors(path, enc_weights_for(synth, cfg_name, 0), cfg.metadata())
+        _ENC[cfg_name] = pkg.HipSpeechTokenizer.load(path, device=0)
+    return _ENC[cfg_name]
+
+
+def check_codes_against_oracle(o, cfg, audio, got, ids):
+    """got == oracle codes except at near-ties; returns the agreement rate."""
+    ref = o.encode(audio)
+    assert got.shape == ref.shape
+    agree = float((got == ref).all(axis=1).mean()) if len(ref) else 1.0
+    bad = np.nonzero((got != ref).any(axis=1))[0]
+    if bad.size:
+        psem, pac = o.stage(audio, ids["proj_sem"]), o.stage(audio, ids["proj_ac"])
+        n_sem = min(cfg.n_semantic, got.shape[1])
+        for t in bad:
+            q = int(np.nonzero(got[t] != ref[t])[0][0])          # first differing layer of the frame
+            group, layer = (0, q) if q < n_sem else (1, q - n_sem)
+            x = (psem if group == 0 else pac)[:, t].astype(np.float32).copy()
+            first = 0 if group == 0 else n_sem
+            for l in range(layer):                               # residual before the differing layer (same codes so far)
+                x = x - o.embed(group, l)[ref[t, first + l]]
+            d = o.distances(group, layer, x)
+            gap = float(d[got[t, q]] - d[ref[t, q]])
+            assert gap <= 1e-3 * max(1.0, float(abs(d[ref[t, q]]))), (t, q, gap)
+    return agree
+
+
+def stage_ids(cfg):
+    nb = len(cfg.ratios)
+    return {"seanet": 1 + 2 * nb, "transformer": 1 + 2 * nb + cfg.num_layers, "latent": 2 + 2 * nb + cfg.num_layers,
+            "proj_sem": 3 + 2 * nb + cfg.num_layers, "proj_ac": 4 + 2 * nb + cfg.num_layers}
+
+
+@pytest.mark.parametrize("cfg_name,n", [("ENC_SMALL", 1920 * 9 + 300), ("ENC_ODD", 1920 * 6 + 1)])
+def test_every_stage_matches_the_oracle(pkg, synth, eo, cfg_name, n):
+    cfg = getattr(synth, cfg_name)
+    e = enc_for(pkg, synth, cfg_name)
+    o = enc_oracle_for(eo, synth, cfg_name, 0)
+    audio = synth.make_audio(n, 17)
+    assert e.n_stages == o.n_stages
+    for s in range(e.n_stages):
+        ref = o.stage(audio, s)
+        got = e.stage(audio, s)
+        assert got.shape == ref.shape, s
+        peak = max(1.0, float(np.abs(ref).max()))
+        assert np.abs(got - ref).max() <= 1e-3 * peak, (s, float(np.abs(got - ref).max()))
+        assert snr_db(ref, got) >= 60.0, (s, snr_db(ref, got))
+
+
+@pytest.mark.parametrize("cfg_name", ["ENC_SMALL", "ENC_ODD"])
+def test_quantiser_is_bit_exact_on_the_gpu_latent(pkg, synth, eo, cfg_name):
+    cfg = getattr(synth, cfg_name)
+    e = enc_for(pkg, synth, cfg_name)
+    o = enc_oracle_for(eo, synth, cfg_name, 0)
+    audio = synth.make_audio(1920 * 50 + 77, 23)
+    codes = e.encode(audio)
+    assert codes.dtype == np.int64 and codes.shape == (50, min(16, cfg.n_semantic + cfg.n_acoustic))
+    lat = e.stage(audio, stage_ids(cfg)["latent"])
+    assert np.array_equal(o.quantize(lat), codes)
+    assert codes.min() >= 0 and codes.max() < cfg.codebook_size
+
+
+@pytest.mark.parametrize("cfg_name", ["ENC_SMALL", "ENC_ODD"])
+def test_codes_match_oracle_up_to_near_ties(pkg, synth, eo, cfg_name):
+    cfg = getattr(synth, cfg_name)
+    e = enc_for(pkg, synth, cfg_name)
+    o = enc_oracle_for(eo, synth, cfg_name, 0)
+    audio = synth.make_audio(1920 * 60, 31)
+    agree = check_codes_against_oracle(o, cfg, audio, e.encode(audio), stage_ids(cfg))
+    assert agree >= 0.9, agree
+
+
+def test_matches_upstream_mimi_golden(pkg, synth, eo):
+    """The committed vectors of transformers' MimiModel (tools/gen_encoder_golden.py) against the GPU path."""
+    g = load_golden("encoder_mimi_small")
+    cfg = synth.ENC_SMALL
+    e = enc_for(pkg, synth, "ENC_SMALL")
+    ids = stage_ids(cfg)
+    for name in ("seanet", "transformer", "latent"):
+        got = e.stage(g["audio"], ids[name])
+        assert np.abs(got - g[name]).max() <= 1e-3 * max(1.0, np.abs(g[name]).max()), name
+    o = enc_oracle_for(eo, synth, "ENC_SMALL", 0)
+    got = e.encode(g["audio"])
+    if not np.array_equal(got, g["codes"]):
+        check_codes_against_oracle(o, cfg, g["audio"], got, ids)
+
+
+def test_lengths_errors_and_determinism(pkg, synth, eo):
+    cfg = synth.ENC_SMALL
+    e = enc_for(pkg, synth, "ENC_SMALL")
+    assert e.samples_per_frame == 1920 and e.n_codebooks == 16
+    for n in (1920, 1921, 3839, 3840, 5000):
+        a = synth.make_audio(n, n)
+        c1 = e.encode(a)
+        assert c1.shape == (n // 1920, 16) and e.n_frames(n) == n // 1920
+        assert np.array_equal(c1, e.encode(a))
+    with pytest.raises(pkg.HipVocError):
+        e.encode(synth.make_audio(1919, 0))
+    with pytest.raises(pkg.HipVocError):
+        e.encode(np.zeros(0, dtype=np.float32))
+    # the handle keeps working after an error, and the vocoder entry points refuse it
+    assert e.encode(synth.make_audio(1920 * 2, 1)).shape == (2, 16)
+    out = np.empty(16, dtype=np.float32)
+    codes = np.zeros(16, dtype=np.int64)
+    import ctypes as C
+    n = C.c_size_t(0)
+    assert e._L.hipvoc_decode(e._h, codes.ctypes.data, 1, out.ctypes.data, out.size, C.byref(n)) < 0
+
+
+def test_batch_is_bitwise_equal_to_single_clips_and_causal(pkg, synth):
+    e = enc_for(pkg, synth, "ENC_SMALL")
+    clips = [synth.make_audio(n, 100 + i) for i, n in enumerate((1920 * 7 + 5, 1920 * 3, 1920 * 12 + 1900, 1920))]
+    outs = e.encode_batch(clips)
+    for a, got in zip(clips, outs):
+        assert np.array_equal(got, e.encode(a))
+    # causality: a prefix's frames do not change when audio is appended
+    long = clips[2]
+    assert np.array_equal(e.encode(long[: 1920 * 5]), outs[2][:5])
+
+
+def test_encode_samples_mono_mix_and_resample(pkg, synth, eo):
+    e = enc_for(pkg, synth, "ENC_SMALL")
+    rng = np.random.default_rng(5)
+    x16 = (0.3 * rng.standard_normal(16000 * 2)).astype(np.float32)
+    assert np.array_equal(pkg.encoder.resample(x16, 16000, 24000), eo.resample(x16, 16000, 24000))
+    stereo = np.stack([x16, -0.5 * x16], axis=1).reshape(-1)
+    mono = ((x16 + (-0.5 * x16)) / np.float32(2)).astype(np.float32)
+    want = e.encode(eo.resample(mono, 16000, 24000))
+    assert np.array_equal(e.encode_samples(stereo, 16000, channels=2), want)
+
+
+def test_encode_then_decode_round_trip_runs(pkg, synth):
+    """Encoder output is valid vocoder input ([n,16] int64 in range): the two halves of the tokenizer compose.  (With
+    random weights the reconstruction is meaningless; this checks shapes, ranges and lengths only.)"""
+    cfg = synth.ENC_FULL
+    path = os.path.join(tempfile.gettempdir(), "hipenc_test_ENC_FULL_0.safetensors")
+    if not os.path.exists(path):
+        synth.save_safetensors(path, synth.make_encoder_weights(cfg, 0), cfg.metadata())
+    e = pkg.HipSpeechTokenizer.load(path, device=0)
+    audio = synth.make_audio(24000 * 3, 9)
+    codes = e.encode(audio)
+    assert codes.shape == (37, 16) and codes.min() >= 0 and codes.max() < 2048
+    dpath = os.path.join(tempfile.gettempdir(), "hipvoc_test_FULL_0.safetensors")
+    if not os.path.exists(dpath):
+        synth.save_safetensors(dpath, synth.make_weights(synth.FULL, 0), synth.FULL.metadata())
+    v = pkg.HipVocoder.load(dpath, device=0, unit_frames=64)
+    wav = v.synthesize(codes)
+    assert wav.size == 37 * 1920 and np.isfinite(wav).all()
