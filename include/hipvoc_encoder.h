@@ -43,6 +43,11 @@ int hipvoc_enc_encode(void *h, const float *audio, int64_t n_samples, int64_t *c
 int hipvoc_enc_encode_batch(void *h, const float *const *audio, const int64_t *n_samples, int B, int64_t *const *codes,
                             const size_t *codes_cap, int64_t *n_frames);
 
+/* Device-resident form (throughput path; asynchronous on the handle's stream, complete after hipvoc_sync()):
+ * B clips of exactly n_samples each at d_audio + i*stride (floats, device memory) -> d_codes[B][n_frames][n_codebooks]
+ * (i64, device memory).  No counterpart in the reference. */
+int hipvoc_enc_encode_device(void *h, const float *d_audio, int B, int64_t n_samples, size_t stride, int64_t *d_codes);
+
 /* Parity hooks (tests only): stage numbering of oracle/enc_oracle.c (0 initial conv; 1+2i residual block i; 2+2i
  * down conv i; then the final conv, the transformer layers, the downsample conv, the semantic and the acoustic
  * input projections); out[C][L] row-major. */

@@ -11,7 +11,7 @@
 //         -> 8 x { LayerNorm, QKV, RoPE sliding-window attention, O, layer scale, +; LayerNorm, fc1, tanh-GELU, fc2, scale, + }
 //         -> conv(k=4, stride 2) -> RVQ encode (1 semantic + 15 acoustic codebooks of the 32).
 // Every conv / linear is conv_gemm (MFMA); a strided conv runs as a 2-tap conv over the space-to-depth form of its
-// input (launch_s2d); the nearest-codeword search is rvq_encode_kernel (bit-exact contract with oracle/enc_oracle.c).
+// input (launch_s2d); the nearest-codeword search is rvq_encode_kernel (bit-exact contract with the encoder test oracle).
 
 namespace hipvoc {
 
@@ -29,6 +29,7 @@ struct EncModel {
     int rope_cap = 0;
     std::map<std::pair<int, long>, std::unique_ptr<Plan>> plans;
     long long *d_codes = nullptr; size_t d_codes_cap = 0;
+    long long *cur_codes_out = nullptr;      // per-call binding: where the search writes (null: d_codes)
     double macs_per_sample = 0;
 
     int64_t n_frames(int64_t n) const {
@@ -246,7 +247,7 @@ static bool enc_rope(Ctx *c, EncModel *m, int T) {
 }
 
 // Plan for G utterances of n samples each (shorter ones are zero-padded at the END by the caller: every layer is
-// causal, so their frames are unaffected).  Stage numbering = oracle/enc_oracle.c.
+// causal, so their frames are unaffected).  Stage numbering = the encoder test oracle.
 static Plan *enc_get_plan(Ctx *c, EncModel *m, int G, long n) {
     auto key = std::make_pair(G, n);
     auto it = m->plans.find(key);
@@ -348,7 +349,7 @@ static Plan *enc_get_plan(Ctx *c, EncModel *m, int G, long n) {
         b.add("enc_rvq_encode", "rvq_encode_kernel", (double)G * T * ((double)nq * m->cb_size * m->D + 2.0 * m->D * D),
               [a, mm](hipStream_t s) {
                   RvqEncArgs aa = a;
-                  aa.codes = mm->d_codes;
+                  aa.codes = mm->cur_codes_out ? mm->cur_codes_out : mm->d_codes;
                   return launch_rvq_encode(aa, s);
               });
         b.mark(st++, proj, m->D, T, Tp);                          // semantic projection
@@ -359,11 +360,12 @@ static Plan *enc_get_plan(Ctx *c, EncModel *m, int G, long n) {
     return raw;
 }
 
+// d_audio != null: B equal-length clips already in HBM (row stride d_stride floats), codes to d_codes_out
 static int enc_run(Ctx *c, EncModel *m, const float *const *audio, const int64_t *n_samples, int B, int stop_stage, const Step **stopped,
-                   Plan **plan_out) {
+                   Plan **plan_out, const float *d_audio_in = nullptr, size_t d_stride = 0, long long *d_codes_out = nullptr) {
     long n = 0;
     for (int i = 0; i < B; i++) {
-        if (n_samples[i] < 0 || !audio[i]) { c->err = "bad argument"; return HIPVOC_E_ARG; }
+        if (n_samples[i] < 0 || (!d_audio_in && !audio[i])) { c->err = "bad argument"; return HIPVOC_E_ARG; }
         n = std::max<long>(n, (long)n_samples[i]);
     }
     if (m->n_frames(n) < 1) { c->err = fmt("audio too short: %ld samples give no frame (one frame = %d samples)", n, m->samples_per_frame()); return HIPVOC_E_ARG; }
@@ -372,12 +374,18 @@ static int enc_run(Ctx *c, EncModel *m, const float *const *audio, const int64_t
     if (!p) { if (c->err.empty()) c->err = "workspace allocation failed"; return HIPVOC_E_HIP; }
     const int Lp0 = (int)rupl(n, 4);
     float *d_audio = p->enc_audio;
-    HIPCHK(hipMemsetAsync(d_audio, 0, (size_t)B * Lp0 * sizeof(float), c->stream));
-    for (int i = 0; i < B; i++)
-        if (n_samples[i])
-            HIPCHK(hipMemcpyAsync(d_audio + (size_t)i * Lp0, audio[i], (size_t)n_samples[i] * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    if (d_audio_in) {
+        HIPCHK(hipMemcpy2DAsync(d_audio, (size_t)Lp0 * sizeof(float), d_audio_in, d_stride * sizeof(float), (size_t)n * sizeof(float), B,
+                                hipMemcpyDeviceToDevice, c->stream));
+    } else {
+        HIPCHK(hipMemsetAsync(d_audio, 0, (size_t)B * Lp0 * sizeof(float), c->stream));
+        for (int i = 0; i < B; i++)
+            if (n_samples[i])
+                HIPCHK(hipMemcpyAsync(d_audio + (size_t)i * Lp0, audio[i], (size_t)n_samples[i] * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    }
+    m->cur_codes_out = d_codes_out;
     const size_t ncodes = (size_t)B * p->T * (m->n_sem + m->n_ac);
-    if (m->d_codes_cap < ncodes) {
+    if (!d_codes_out && m->d_codes_cap < ncodes) {
         if (m->d_codes) HIPCHK(hipFree(m->d_codes));
         m->d_codes = nullptr; m->d_codes_cap = 0;
         HIPCHK(hipMalloc((void **)&m->d_codes, ncodes * sizeof(long long)));
@@ -477,6 +485,14 @@ int hipvoc_enc_encode(void *h, const float *audio, int64_t n_samples, int64_t *c
     int rc = hipvoc_enc_encode_batch(h, ap, &n_samples, 1, cp, &codes_cap, &nf);
     if (n_frames) *n_frames = nf;
     return rc;
+}
+
+int hipvoc_enc_encode_device(void *h, const float *d_audio, int B, int64_t n_samples, size_t stride, int64_t *d_codes) {
+    ENC(h)
+    if (!d_audio || !d_codes || B < 1 || n_samples < 1 || stride < (size_t)n_samples) { c->err = "bad argument"; return HIPVOC_E_ARG; }
+    std::vector<int64_t> ns((size_t)B, n_samples);
+    std::vector<const float *> none((size_t)B, nullptr);
+    return enc_run(c, m, none.data(), ns.data(), B, -1, nullptr, nullptr, d_audio, stride, (long long *)d_codes);
 }
 
 int hipvoc_enc_num_stages(void *h) {

@@ -1087,7 +1087,11 @@ int hipvoc_decode_units_device(void *h, const int64_t *d_codes, int n_units, flo
 }
 
 int hipvoc_sync(void *h) {
-    DEC(h);
+    CTX(h)
+    if (c->is_encoder) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        return HIPVOC_OK;
+    }
     return sync_check(c);
 }
 

@@ -120,7 +120,7 @@ struct RvqEncArgs {
     float *proj;           // optional [2*D][G][Lp]: the projected latents (debug) or null
     int dim, D, cb_size, n_sem, n_ac, T, Lp, G;
 };
-// Nearest-codeword search, bit-exact contract of oracle/enc_oracle.c (k-ascending fmaf chains, first minimum)
+// Nearest-codeword search, bit-exact contract of the encoder test oracle (k-ascending fmaf chains, first minimum)
 hipError_t launch_rvq_encode(const RvqEncArgs &a, hipStream_t s);
 
 }  // namespace hipvoc

@@ -79,66 +79,144 @@ hipError_t launch_layernorm(const float *x, float *y, const float *w, const floa
 }
 
 // ---------------------------------------------------------------------------------------------------
-// RVQ encode (speech_tokenizer.rs:494-509, 536-556, 581-585): one workgroup per frame.
+// RVQ encode (speech_tokenizer.rs:494-509, 536-556, 581-585): a workgroup takes FB frames through every layer.
 //   proj = input_proj * h (1x1 conv, no bias), then per layer: nearest codeword of the residual, residual -= codeword.
-// BIT-EXACT CONTRACT (oracle/enc_oracle.c: linear, nearest, rvq_encode): every dot product is a k-ascending fmaf
-// chain from 0; |x|^2 and |e|^2 are k-ascending sums of ROUNDED squares; distance = (|x|^2 + |e|^2) - 2*<x,e>;
+// BIT-EXACT CONTRACT (the encoder test oracle: linear, nearest, rvq_encode): every dot product is a k-ascending
+// fmaf chain from 0; |x|^2 and |e|^2 are k-ascending sums of ROUNDED squares; distance = (|x|^2 + |e|^2) - 2*<x,e>;
 // argmin = the first minimum.  Contraction is ruled out by spelling every operation as an intrinsic.
-// Thread c walks codewords c, c+256, ... of the transposed codebook (coalesced); the residual lives in LDS.
+// The chains fix the order along k only, so the search is a register-tiled VALU GEMM: a thread owns 8 consecutive
+// codewords x FB frames (64 independent chains); per k it loads its 8 codeword values once (transposed codebook:
+// 32 contiguous bytes per thread) and the FB residual values as two broadcast ds_read_b128.  (MFMA is not an option
+// here: its internal summation is not an fmaf chain.)
 // ---------------------------------------------------------------------------------------------------
+static constexpr int FB = 8;    // frames per workgroup
+static constexpr int CPT = 8;   // consecutive codewords per thread
+
 __global__ __launch_bounds__(256) void rvq_encode_kernel(RvqEncArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *hs = smem;              // [dim]
-    float *xs = hs + a.dim;        // [D] residual
-    __shared__ float bd[256];
-    __shared__ int bi[256];
+    float *hs = smem;                  // [dim][FB]
+    float *xs = hs + a.dim * FB;       // [D][FB] residual
+    __shared__ float bd[FB][256];
+    __shared__ int bi[FB][256];
+    __shared__ float xsq_s[FB];
+    __shared__ int code_s[FB];
     const int tid = threadIdx.x;
-    const int u = blockIdx.x / a.T, t = blockIdx.x - u * a.T;
-    const long cs = (long)a.G * a.Lp, base = (long)u * a.Lp + t;
-    for (int k = tid; k < a.dim; k += 256) hs[k] = a.h[(long)k * cs + base];
+    const long nframes = (long)a.G * a.T, f0 = (long)blockIdx.x * FB;
+    const long cs = (long)a.G * a.Lp;
+    const int nq = a.n_sem + a.n_ac;
+    for (int i = tid; i < a.dim * FB; i += 256) {
+        const int k = i / FB, f = i - k * FB;
+        const long g = f0 + f;
+        float v = 0.0f;
+        if (g < nframes) {
+            const long u = g / a.T, t = g - u * a.T;
+            v = a.h[(long)k * cs + u * a.Lp + t];
+        }
+        hs[i] = v;
+    }
     __syncthreads();
-    long long *cp = a.codes + ((long)u * a.T + t) * (a.n_sem + a.n_ac);
     for (int group = 0; group < 2; group++) {
         const int nl = group ? a.n_ac : a.n_sem;
         if (!nl) continue;
         const float *wp = a.wp_t + (long)group * a.dim * a.D;
         for (int d = tid; d < a.D; d += 256) {
-            float p = 0.0f;
-            for (int k = 0; k < a.dim; k++) p = __builtin_fmaf(wp[(long)k * a.D + d], hs[k], p);
-            xs[d] = p;
-            if (a.proj) a.proj[(long)(group * a.D + d) * cs + base] = p;
+            float p[FB];
+#pragma unroll
+            for (int f = 0; f < FB; f++) p[f] = 0.0f;
+            for (int k = 0; k < a.dim; k++) {
+                const float w = wp[(long)k * a.D + d];
+                const float4 x0 = *reinterpret_cast<const float4 *>(hs + k * FB), x1 = *reinterpret_cast<const float4 *>(hs + k * FB + 4);
+                const float xv[FB] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+                for (int f = 0; f < FB; f++) p[f] = __builtin_fmaf(w, xv[f], p[f]);
+            }
+#pragma unroll
+            for (int f = 0; f < FB; f++) {
+                xs[d * FB + f] = p[f];
+                const long g = f0 + f;
+                if (a.proj && g < nframes) {
+                    const long u = g / a.T, t = g - u * a.T;
+                    a.proj[(long)(group * a.D + d) * cs + u * a.Lp + t] = p[f];
+                }
+            }
         }
         __syncthreads();
         for (int l = 0; l < nl; l++) {
             const int q = group ? a.n_sem + l : l;
             const float *et = a.emb_t + (long)q * a.D * a.cb_size;
             const float *esq = a.e_sq + (long)q * a.cb_size;
-            float x_sq = 0.0f;
-            for (int d = 0; d < a.D; d++) x_sq = __fadd_rn(x_sq, __fmul_rn(xs[d], xs[d]));
-            float best = INFINITY;
-            int besti = 0x7fffffff;
-            for (int c = tid; c < a.cb_size; c += 256) {
-                float xe = 0.0f;
-                for (int d = 0; d < a.D; d++) xe = __builtin_fmaf(xs[d], et[(long)d * a.cb_size + c], xe);
-                float dist = __fsub_rn(__fadd_rn(x_sq, esq[c]), __fmul_rn(xe, 2.0f));
-                if (dist < best) { best = dist; besti = c; }      // ascending c: the first minimum of this thread
+            if (tid < FB) {
+                float s = 0.0f;
+                for (int d = 0; d < a.D; d++) { const float v = xs[d * FB + tid]; s = __fadd_rn(s, __fmul_rn(v, v)); }
+                xsq_s[tid] = s;
             }
-            bd[tid] = best;
-            bi[tid] = besti;
+            __syncthreads();
+            float best[FB];
+            int besti[FB];
+#pragma unroll
+            for (int f = 0; f < FB; f++) { best[f] = INFINITY; besti[f] = 0x7fffffff; }
+            const bool vec = (a.cb_size & 7) == 0;
+            for (int c0 = tid * CPT; c0 < a.cb_size; c0 += 256 * CPT) {      // ascending chunks: first minimum is kept
+                float acc[CPT][FB];
+#pragma unroll
+                for (int j = 0; j < CPT; j++)
+#pragma unroll
+                    for (int f = 0; f < FB; f++) acc[j][f] = 0.0f;
+                for (int d = 0; d < a.D; d++) {
+                    float e[CPT];
+                    const float *ep = et + (long)d * a.cb_size + c0;
+                    if (vec) {
+                        const float4 e0 = *reinterpret_cast<const float4 *>(ep), e1 = *reinterpret_cast<const float4 *>(ep + 4);
+                        e[0] = e0.x; e[1] = e0.y; e[2] = e0.z; e[3] = e0.w; e[4] = e1.x; e[5] = e1.y; e[6] = e1.z; e[7] = e1.w;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < CPT; j++) e[j] = c0 + j < a.cb_size ? ep[j] : 0.0f;
+                    }
+                    const float4 x0 = *reinterpret_cast<const float4 *>(xs + d * FB), x1 = *reinterpret_cast<const float4 *>(xs + d * FB + 4);
+                    const float xv[FB] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+                    for (int j = 0; j < CPT; j++)
+#pragma unroll
+                        for (int f = 0; f < FB; f++) acc[j][f] = __builtin_fmaf(xv[f], e[j], acc[j][f]);
+                }
+#pragma unroll
+                for (int j = 0; j < CPT; j++) {
+                    if (c0 + j < a.cb_size) {
+                        const float es = esq[c0 + j];
+#pragma unroll
+                        for (int f = 0; f < FB; f++) {
+                            const float dist = __fsub_rn(__fadd_rn(xsq_s[f], es), __fmul_rn(acc[j][f], 2.0f));
+                            if (dist < best[f]) { best[f] = dist; besti[f] = c0 + j; }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int f = 0; f < FB; f++) { bd[f][tid] = best[f]; bi[f][tid] = besti[f]; }
             __syncthreads();
             for (int sft = 128; sft > 0; sft >>= 1) {
                 if (tid < sft) {
-                    float od = bd[tid + sft];
-                    int oi = bi[tid + sft];
-                    if (od < bd[tid] || (od == bd[tid] && oi < bi[tid])) { bd[tid] = od; bi[tid] = oi; }
+#pragma unroll
+                    for (int f = 0; f < FB; f++) {
+                        const float od = bd[f][tid + sft];
+                        const int oi = bi[f][tid + sft];
+                        if (od < bd[f][tid] || (od == bd[f][tid] && oi < bi[f][tid])) { bd[f][tid] = od; bi[f][tid] = oi; }
+                    }
                 }
                 __syncthreads();
             }
-            int code = bi[0];
-            if (code == 0x7fffffff) code = 0;                      // every distance NaN / +inf: argmin of candle returns 0
-            if (tid == 0) cp[q] = code;
-            __syncthreads();                                       // bd / bi are rewritten by the next layer
-            for (int d = tid; d < a.D; d += 256) xs[d] = __fsub_rn(xs[d], et[(long)d * a.cb_size + code]);
+            if (tid < FB) {
+                int code = bi[tid][0];
+                if (code == 0x7fffffff) code = 0;                  // every distance NaN / +inf: argmin of candle returns 0
+                code_s[tid] = code;
+                const long g = f0 + tid;
+                if (g < nframes) a.codes[g * nq + q] = code;       // codes[u][t][q], frames are (u, t) flattened
+            }
+            __syncthreads();
+            for (int d = tid; d < a.D; d += 256)
+#pragma unroll
+                for (int f = 0; f < FB; f++)
+                    xs[d * FB + f] = __fsub_rn(xs[d * FB + f], et[(long)d * a.cb_size + code_s[f]]);
             __syncthreads();
         }
     }
@@ -146,9 +224,10 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(RvqEncArgs a) {
 
 hipError_t launch_rvq_encode(const RvqEncArgs &a, hipStream_t s) {
     if (a.G <= 0 || a.T <= 0) return hipSuccess;
-    size_t lds = sizeof(float) * ((size_t)a.dim + a.D);
-    if (lds > 60 * 1024 || a.cb_size < 1 || a.D < 1) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(rvq_encode_kernel, dim3((unsigned)(a.G * a.T)), dim3(256), lds, s, a);
+    size_t lds = sizeof(float) * FB * ((size_t)a.dim + a.D);
+    if (lds > 40 * 1024 || a.cb_size < 1 || a.D < 1 || ((uintptr_t)a.emb_t & 15)) return hipErrorInvalidValue;
+    const long nframes = (long)a.G * a.T;
+    hipLaunchKernelGGL(rvq_encode_kernel, dim3((unsigned)((nframes + FB - 1) / FB)), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 

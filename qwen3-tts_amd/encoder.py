@@ -20,7 +20,8 @@ SAMPLE_RATE = 24000             # speech_tokenizer.rs:15
 
 ENC_EXPORTS = [
     "hipvoc_enc_load", "hipvoc_enc_n_codebooks", "hipvoc_enc_samples_per_frame", "hipvoc_enc_n_frames",
-    "hipvoc_enc_macs_per_sample", "hipvoc_enc_encode", "hipvoc_enc_encode_batch", "hipvoc_enc_num_stages",
+    "hipvoc_enc_macs_per_sample", "hipvoc_enc_encode", "hipvoc_enc_encode_batch", "hipvoc_enc_encode_device",
+    "hipvoc_enc_num_stages",
     "hipvoc_enc_debug_stage", "hipvoc_resample_linear",
 ]
 
@@ -42,6 +43,7 @@ def _lib():
         L.hipvoc_enc_macs_per_sample.argtypes = [vp]
         L.hipvoc_enc_encode.argtypes = [vp, vp, C.c_int64, vp, sz, C.POINTER(C.c_int64)]
         L.hipvoc_enc_encode_batch.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp]
+        L.hipvoc_enc_encode_device.argtypes = [vp, vp, C.c_int, C.c_int64, sz, vp]
         L.hipvoc_enc_num_stages.argtypes = [vp]
         L.hipvoc_enc_debug_stage.argtypes = [vp, vp, C.c_int64, C.c_int, vp, sz, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
         L.hipvoc_resample_linear.restype = C.c_int64
@@ -121,6 +123,13 @@ class HipSpeechTokenizer:
         nf = (C.c_int64 * B)()
         self._check(self._L.hipvoc_enc_encode_batch(self._h, ap, ns, B, cp, caps, nf))
         return [o[: nf[i]] for i, o in enumerate(outs)]
+
+    def encode_device(self, d_audio_ptr: int, B: int, n_samples: int, stride: int, d_codes_ptr: int):
+        """B equal-length clips resident in HBM -> codes in HBM (asynchronous; .sync() to wait)."""
+        self._check(self._L.hipvoc_enc_encode_device(self._h, d_audio_ptr, B, n_samples, stride, d_codes_ptr))
+
+    def sync(self):
+        self._check(self._L.hipvoc_sync(self._h))
 
     def encode_samples(self, samples, sample_rate: int, channels: int = 1) -> np.ndarray:
         """What encode_wav does once the file is decoded (698-720): interleaved channels are averaged to mono, other

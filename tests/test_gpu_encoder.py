@@ -183,3 +183,36 @@ def test_encode_then_decode_round_trip_runs(pkg, synth):
     v = pkg.HipVocoder.load(dpath, device=0, unit_frames=64)
     wav = v.synthesize(codes)
     assert wav.size == 37 * 1920 and np.isfinite(wav).all()
+
+
+def test_full_size_model_parity_and_device_entry_point(pkg, synth, eo):
+    """The real dimensions (56 M parameters, 2048-entry codebooks, window 250) on a 3 s clip: float stages within the
+    fp32 gates, quantiser bit-exact on the GPU latent, codes equal to the oracle's up to near-ties; the
+    device-resident entry point gives the same codes as the host one."""
+    import torch
+    cfg = synth.ENC_FULL
+    path = os.path.join(tempfile.gettempdir(), "hipenc_test_ENC_FULL_0.safetensors")
+    W = enc_weights_for(synth, "ENC_FULL", 0)
+    if not os.path.exists(path):
+        synth.save_safetensors(path, W, cfg.metadata())
+    e = pkg.HipSpeechTokenizer.load(path, device=0)
+    o = enc_oracle_for(eo, synth, "ENC_FULL", 0)
+    audio = synth.make_audio(24000 * 3, 41)
+    ids = stage_ids(cfg)
+    for name in ("seanet", "transformer", "latent", "proj_sem", "proj_ac"):
+        ref, got = o.stage(audio, ids[name]), e.stage(audio, ids[name])
+        assert got.shape == ref.shape
+        assert np.abs(got - ref).max() <= 1e-3 * max(1.0, float(np.abs(ref).max())), name
+        assert snr_db(ref, got) >= 60.0, (name, snr_db(ref, got))
+    codes = e.encode(audio)
+    assert np.array_equal(o.quantize(e.stage(audio, ids["latent"])), codes)
+    agree = check_codes_against_oracle(o, cfg, audio, codes, ids)
+    assert agree >= 0.9, agree
+    B, n = 3, audio.size
+    d_audio = torch.from_numpy(np.stack([audio, synth.make_audio(n, 42), audio])).cuda()
+    d_codes = torch.empty((B, e.n_frames(n), 16), dtype=torch.int64, device="cuda")
+    e.encode_device(d_audio.data_ptr(), B, n, n, d_codes.data_ptr())
+    e.sync()
+    out = d_codes.cpu().numpy()
+    assert np.array_equal(out[0], codes) and np.array_equal(out[2], codes)
+    assert np.array_equal(out[1], e.encode(synth.make_audio(n, 42)))

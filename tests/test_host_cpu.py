@@ -11,7 +11,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("header,exports", [("hipvoc.h", "hipvoc.EXPORTS"), ("hipvoc_wire.h", "wire.WIRE_EXPORTS")])
+@pytest.mark.parametrize("header,exports", [("hipvoc.h", "hipvoc.EXPORTS"), ("hipvoc_wire.h", "wire.WIRE_EXPORTS"),
+                                            ("hipvoc_encoder.h", "encoder.ENC_EXPORTS")])
 def test_library_exports_every_declared_symbol(pkg, header, exports):
     hdr = open(os.path.join(ROOT, "include", header)).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
@@ -33,6 +34,10 @@ def test_no_cpu_fallback(pkg, tmp_path):
     pkg.synth.save_safetensors(path, W, pkg.synth.ODD.metadata())
     with pytest.raises(pkg.HipVocError):
         pkg.HipVocoder.load(path)
+    EW = pkg.synth.make_encoder_weights(pkg.synth.ENC_ODD, 0)
+    pkg.synth.save_safetensors(path, EW, pkg.synth.ENC_ODD.metadata())
+    with pytest.raises(pkg.HipVocError):
+        pkg.HipSpeechTokenizer.load(path)
 
 
 def test_product_never_touches_the_oracle():
@@ -40,7 +45,7 @@ def test_product_never_touches_the_oracle():
         for f in files:
             if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")) or f == "Makefile":
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
-                assert "voc_oracle" not in text and "oracle/" not in text, os.path.join(dirpath, f)
+                assert "voc_oracle" not in text and "enc_oracle" not in text and "oracle/" not in text, os.path.join(dirpath, f)
 
 
 def test_safetensors_writer_matches_the_reference_package(pkg, tmp_path):
