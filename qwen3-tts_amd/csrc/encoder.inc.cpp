@@ -319,7 +319,7 @@ static Plan *enc_get_plan(Ctx *c, EncModel *m, int G, long n) {
             float *hh = h;
             b.add("enc_layernorm", "layernorm_kernel", 0, [=](hipStream_t s) { return launch_layernorm(hh, xn, ly.ln1w, ly.ln1b, D, P, eps, s); });
             b.gemm("enc_qkv", ly.qkv, xn, T, Tp, qkv, Tp, nullptr, nullptr, nullptr, ACT_NONE);
-            b.add("enc_attention", "attention_kernel<16>", (double)G * nh * T * std::min(T, win) * hd, [=](hipStream_t s) {
+            b.add("enc_attention", attention_kernel_name(hd, T, win), (double)G * nh * T * std::min(T, win) * hd, [=](hipStream_t s) {
                 return launch_attention(qkv, ao, ct, sn, nh, hd, G, T, Tp, win, s);
             });
             b.gemm("enc_o_proj", ly.o, ao, T, Tp, h, Tp, nullptr, h, ly.ls1, ACT_NONE);

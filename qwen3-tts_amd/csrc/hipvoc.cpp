@@ -668,7 +668,7 @@ static Plan *get_plan(Ctx *c, int G, int T, bool debug = false) {
             b.gemm("qkv", ly.qkv, xn, T, Tp, qkv, Tp, nullptr, nullptr, nullptr, ACT_NONE);
             int nh = c->n_heads, hd = c->head_dim, win = c->window;
             const float *ct = c->cos_t, *sn = c->sin_t;
-            b.add("attention", "attention_kernel<32>", (double)G * nh * T * T * hd, [=](hipStream_t s) {
+            b.add("attention", attention_kernel_name(hd, T, win), (double)G * nh * T * T * hd, [=](hipStream_t s) {
                 return launch_attention(qkv, ao, ct, sn, nh, hd, G, T, Tp, win, s);
             });
             b.gemm("o_proj", ly.o, ao, T, Tp, h, Tp, nullptr, h, ly.ls1, ACT_NONE);

@@ -91,6 +91,8 @@ hipError_t launch_rmsnorm(const float *x, float *y, const float *w, int C, long 
 hipError_t launch_attention(const float *qkv, float *out, const float *cos_t, const float *sin_t, int nh, int hd,
                             int G, int T, int Lp, int window, hipStream_t s);
 
+const char *attention_kernel_name(int hd, int T, int window);   // kernel symbol launched for these shapes
+
 // g[i] = silu(g[i]) * u[i]  over n elements
 hipError_t launch_swiglu(float *g, const float *u, long n, hipStream_t s);
 

@@ -654,10 +654,154 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *qkv, float 
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// Attention on the fp32 matrix cores (head_dim 32 or 64): one wave per (unit, head, 32 queries), flash-style over
+// key tiles of 32, in the TRANSPOSED formulation so that every softmax statistic is lane-local:
+//   S^T tile = K_tile (A: rows = keys) x Q^T (B: columns = queries)  -> lane l31 holds ONE query's scores for the
+//   16 keys of its half; running max / sum are per lane (+ one exchange between the two lane halves);
+//   O^T += V^T (A: rows = head dims) x P^T (B): the score accumulator is fed straight back as the B operand -- register
+//   r of lane half h is key (r&3) + 8(r>>2) + 4h of the tile, and the A operand is read from LDS in that key order.
+// RoPE (rotate-half) is applied to q in registers and to k while it is staged.  Mask: kv <= q && kv > q - window.
+// -------------------------------------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(64) void attention_mfma_kernel(const float *qkv, float *out, const float *cos_t,
+                                                            const float *sin_t, int nh, int G, int T, int Lp, int window) {
+    __shared__ float Ks[HD][32];        // [d][key]
+    __shared__ float Vs[32][HD + 1];    // [key][d]
+    constexpr int half = HD / 2;
+    const int u = blockIdx.x, hh = blockIdx.y, q0 = blockIdx.z * 32;
+    const int lane = threadIdx.x, l31 = lane & 31, h = lane >> 5;
+    const long cs = (long)G * Lp, base = (long)u * Lp;
+    const float *qp = qkv + (long)(hh * HD) * cs + base;
+    const float *kp = qkv + (long)((nh + hh) * HD) * cs + base;
+    const float *vp = qkv + (long)((2 * nh + hh) * HD) * cs + base;
+    const int tq = q0 + l31;
+    const bool qok = tq < T;
+    const int tqc = qok ? tq : T - 1;
+    // this lane's query, head dims d = 2*kk + h (the k index the lane supplies to MFMA step kk), RoPE applied
+    float qv[HD / 2];
+#pragma unroll
+    for (int kk = 0; kk < HD / 2; kk++) qv[kk] = qp[(long)(2 * kk + h) * cs + tqc];
+#pragma unroll
+    for (int kk = 0; kk < HD / 4; kk++) {
+        const int d = 2 * kk + h;                         // d < half; its partner d + half is step kk + HD/4
+        const float a = qv[kk], b = qv[kk + HD / 4];
+        const float c = cos_t[tqc * half + d], s = sin_t[tqc * half + d];
+        qv[kk] = a * c + (-b) * s;
+        qv[kk + HD / 4] = b * c + a * s;
+    }
+    f32x16 o[HD / 32];
+#pragma unroll
+    for (int i = 0; i < HD / 32; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[i][r] = 0.0f;
+    float m = -INFINITY, l = 0.0f;
+    const float scaling = 1.0f / sqrtf((float)HD);
+    const int k_lo = max(0, q0 - window + 1);
+    const int qlast = min(q0 + 31, T - 1);
+    for (int kt = k_lo / 32; kt <= qlast / 32; kt++) {
+        __syncthreads();                                   // the previous tile's LDS reads are done
+        {
+            const int key = kt * 32 + l31;
+            const int kc = key < T ? key : T - 1;          // clamped: keys >= T are masked below
+#pragma unroll
+            for (int j = 0; j < HD / 4; j++) {
+                const int d = h * (HD / 4) + j;
+                const float a = kp[(long)d * cs + kc], b = kp[(long)(d + half) * cs + kc];
+                const float c = cos_t[kc * half + d], s = sin_t[kc * half + d];
+                Ks[d][l31] = a * c + (-b) * s;
+                Ks[d + half][l31] = b * c + a * s;
+            }
+#pragma unroll
+            for (int j = 0; j < HD / 2; j++) {
+                const int d = h * (HD / 2) + j;
+                Vs[l31][d] = vp[(long)d * cs + kc];
+            }
+        }
+        __syncthreads();
+        f32x16 sc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) sc[r] = 0.0f;
+#pragma unroll
+        for (int kk = 0; kk < HD / 2; kk++) sc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[2 * kk + h][l31], qv[kk], sc, 0, 0, 0);
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const bool ok = key <= tq && key > tq - window && qok;
+            sc[r] = ok ? sc[r] * scaling : -INFINITY;
+            tmax = fmaxf(tmax, sc[r]);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        const float mn = fmaxf(m, tmax);
+        if (mn != -INFINITY) {                             // (per lane; no MFMA inside the branch)
+            const float alpha = m == -INFINITY ? 0.0f : expf(m - mn);
+            float ps = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                sc[r] = sc[r] == -INFINITY ? 0.0f : expf(sc[r] - mn);
+                ps += sc[r];
+            }
+            l = l * alpha + ps;
+#pragma unroll
+            for (int i = 0; i < HD / 32; i++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) o[i][r] *= alpha;
+            m = mn;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; r++) sc[r] = 0.0f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int kl = (r & 3) + 8 * (r >> 2) + 4 * h;
+#pragma unroll
+            for (int i = 0; i < HD / 32; i++) o[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[kl][i * 32 + l31], sc[r], o[i], 0, 0, 0);
+        }
+    }
+    l += __shfl_xor(l, 32);
+    if (qok) {
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int i = 0; i < HD / 32; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int d = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                out[(long)(hh * HD + d) * cs + base + tq] = o[i][r] * inv;
+            }
+    }
+}
+
+static int attention_use_mfma() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("HIPVOC_ATTN_MFMA"); v = e ? atoi(e) : 1; }
+    return v;
+}
+
+// kernel symbol launched for these shapes (profiling labels)
+const char *attention_kernel_name(int hd, int T, int window) {
+    if (attention_use_mfma() && hd == 64) return "attention_mfma_kernel<64>";
+    if (attention_use_mfma() && hd == 32) return "attention_mfma_kernel<32>";
+    for (int qb = 32; qb >= 8; qb >>= 1) {
+        int nkmax = qb + (window > 1 ? window - 1 : 0);
+        if (nkmax > T) nkmax = T;
+        int NKP = nkmax | 1;
+        size_t lds = sizeof(float) * ((size_t)hd * qb + 2 * (size_t)hd * NKP + (size_t)qb * NKP);
+        if (lds <= 160 * 1024) return qb == 32 ? "attention_kernel<32>" : qb == 16 ? "attention_kernel<16>" : "attention_kernel<8>";
+    }
+    return "attention_kernel<8>";
+}
+
 hipError_t launch_attention(const float *qkv, float *out, const float *cos_t, const float *sin_t, int nh, int hd,
                             int G, int T, int Lp, int window, hipStream_t s) {
-    if (G <= 0) return hipSuccess;
+    if (G <= 0 || T <= 0) return hipSuccess;
     if (hd & 1) return hipErrorInvalidValue;
+    if (attention_use_mfma() && (hd == 64 || hd == 32)) {
+        dim3 g(G, nh, (T + 31) / 32);
+        if (hd == 64) hipLaunchKernelGGL(attention_mfma_kernel<64>, g, dim3(64), 0, s, qkv, out, cos_t, sin_t, nh, G, T, Lp, window);
+        else hipLaunchKernelGGL(attention_mfma_kernel<32>, g, dim3(64), 0, s, qkv, out, cos_t, sin_t, nh, G, T, Lp, window);
+        return hipGetLastError();
+    }
     for (int qb = 32; qb >= 8; qb >>= 1) {
         int nkmax = qb + (window > 1 ? window - 1 : 0);
         if (nkmax > T) nkmax = T;
