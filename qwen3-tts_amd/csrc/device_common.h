@@ -152,12 +152,26 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvGemmArgs &a, const 
             o[q] = (long)c * a.y_cs + (long)m * a.S + ph;
         }
         if (a.S == 1) { cg[0] = n0 + row[0]; cg[1] = n0 + row[4]; }
+        long ro[8];                               // residual offsets (differ from o[] only with s2d)
+#pragma unroll
+        for (int q = 0; q < 8; q++) ro[q] = o[q];
+        if constexpr (ENC) {
+            if (a.s2d > 1) {
+                const int qd = m / a.s2d, j = m - qd * a.s2d;
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const long c = n0 + row[q];
+                    ro[q] = c * a.x_cs + m;
+                    o[q] = (c * a.s2d + j) * a.y_cs + qd;
+                }
+            }
+        }
         float v[8], t[8];
 #pragma unroll
         for (int q = 0; q < 8; q++) v[q] = acc[half * 8 + q];
         if (ru) {
 #pragma unroll
-            for (int q = 0; q < 8; q++) t[q] = ru[ok[q] ? o[q] : 0];
+            for (int q = 0; q < 8; q++) t[q] = ru[ok[q] ? ro[q] : 0];
         }
         if (a.bias) {
 #pragma unroll

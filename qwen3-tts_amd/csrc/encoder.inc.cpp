@@ -248,8 +248,10 @@ static bool enc_rope(Ctx *c, EncModel *m, int T) {
 
 // Plan for G utterances of n samples each (shorter ones are zero-padded at the END by the caller: every layer is
 // causal, so their frames are unaffected).  Stage numbering = the encoder test oracle.
-static Plan *enc_get_plan(Ctx *c, EncModel *m, int G, long n) {
-    auto key = std::make_pair(G, n);
+// Production plans write the input of every strided conv straight from its producer's epilogue (ConvGemmArgs::s2d);
+// debug plans (stage taps want the raw tensors) write the raw tensor and convert it in a separate pass (s2d_kernel).
+static Plan *enc_get_plan(Ctx *c, EncModel *m, int G, long n, bool debug) {
+    auto key = std::make_pair(debug ? -G : G, n);
     auto it = m->plans.find(key);
     if (it != m->plans.end()) return it->second.get();
     std::unique_ptr<Plan> plan(new Plan);
@@ -288,10 +290,13 @@ static Plan *enc_get_plan(Ctx *c, EncModel *m, int G, long n) {
     for (const EncModel::Blk &bl : m->blocks) {
         // ResidualBlock::forward (139-149); ELU is applied where the value is consumed / produced
         b.gemm("enc_res_conv3", bl.c1, h, L, Lp, M, Lp, nullptr, nullptr, nullptr, ACT_ELU, nullptr, nullptr, nullptr, nullptr, 1);
-        b.gemm("enc_res_conv1", bl.c2, M, L, Lp, h, Lp, nullptr, h, nullptr, ACT_NONE);
-        b.mark(st++, h, bl.C, L, Lp);
         const int r = bl.ratio, Lq = L / r, Lqp = rup(std::max(Lq, 1), 4);
-        {
+        if (!debug) {
+            b.gemm("enc_res_conv1", bl.c2, M, L, Lp, SD, Lqp, nullptr, h, nullptr, ACT_ELU, nullptr, nullptr, nullptr, nullptr, 0, r);
+            st++;
+        } else {
+            b.gemm("enc_res_conv1", bl.c2, M, L, Lp, h, Lp, nullptr, h, nullptr, ACT_NONE);
+            b.mark(st++, h, bl.C, L, Lp);
             const float *x = h;
             float *y = SD;
             int C = bl.C, GG = G, LL = L, LLp = Lp;
@@ -306,6 +311,8 @@ static Plan *enc_get_plan(Ctx *c, EncModel *m, int G, long n) {
     std::swap(h, o);
     b.mark(st++, h, m->dim, L, Lp);
     const int D = m->dim;
+    const int dsr = m->ds_stride, dsT = L / dsr, dsTp = rup(std::max(dsT, 1), 4);
+    bool ds_fused = false;
     if (m->n_layers) {
         if (!enc_rope(c, m, L)) return nullptr;
         float *xn = grow(EB_XN, (size_t)D * G * Lp), *qkv = grow(EB_QKV, (size_t)3 * D * G * Lp);
@@ -325,12 +332,18 @@ static Plan *enc_get_plan(Ctx *c, EncModel *m, int G, long n) {
             b.gemm("enc_o_proj", ly.o, ao, T, Tp, h, Tp, nullptr, h, ly.ls1, ACT_NONE);
             b.add("enc_layernorm", "layernorm_kernel", 0, [=](hipStream_t s) { return launch_layernorm(hh, xn, ly.ln2w, ly.ln2b, D, P, eps, s); });
             b.gemm("enc_fc1", ly.fc1, xn, T, Tp, ffb, Tp, nullptr, nullptr, nullptr, ACT_GELU_TANH);
-            b.gemm("enc_fc2", ly.fc2, ffb, T, Tp, h, Tp, nullptr, h, ly.ls2, ACT_NONE);
-            b.mark(st++, h, D, T, Tp);
+            if (!debug && &ly == &m->layers.back()) {      // the last layer's output only feeds the stride-2 conv
+                b.gemm("enc_fc2", ly.fc2, ffb, T, Tp, SD, dsTp, nullptr, h, ly.ls2, ACT_NONE, nullptr, nullptr, nullptr, nullptr, 0, dsr);
+                ds_fused = true;
+                st++;
+            } else {
+                b.gemm("enc_fc2", ly.fc2, ffb, T, Tp, h, Tp, nullptr, h, ly.ls2, ACT_NONE);
+                b.mark(st++, h, D, T, Tp);
+            }
         }
     }
-    const int r = m->ds_stride, T = L / r, Tp = rup(std::max(T, 1), 4);
-    {
+    const int r = dsr, T = dsT, Tp = dsTp;
+    if (!ds_fused) {
         const float *x = h;
         float *y = SD;
         int GG = G, LL = L, LLp = Lp;
@@ -370,7 +383,7 @@ static int enc_run(Ctx *c, EncModel *m, const float *const *audio, const int64_t
     }
     if (m->n_frames(n) < 1) { c->err = fmt("audio too short: %ld samples give no frame (one frame = %d samples)", n, m->samples_per_frame()); return HIPVOC_E_ARG; }
     if (n > 0x7ffffff0L / 4) { c->err = "audio too long for one pass"; return HIPVOC_E_ARG; }
-    Plan *p = enc_get_plan(c, m, B, n);
+    Plan *p = enc_get_plan(c, m, B, n, stop_stage >= 0);
     if (!p) { if (c->err.empty()) c->err = "workspace allocation failed"; return HIPVOC_E_HIP; }
     const int Lp0 = (int)rupl(n, 4);
     float *d_audio = p->enc_audio;

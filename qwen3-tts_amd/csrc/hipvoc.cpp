@@ -578,9 +578,10 @@ struct PlanBuilder {
     // x[Cin][G][Lpi] -> y[N/S][G][Lpo]
     void gemm(const char *name, const Gemm &g, const float *x, int Lin, int Lpi, float *y, int Lpo, const Snake *sn,
               const float *res, const float *rscale, int act, const Snake *post = nullptr, float *y2 = nullptr,
-              const unsigned short *xb = nullptr, unsigned short *yb = nullptr, int in_elu = 0) {
+              const unsigned short *xb = nullptr, unsigned short *yb = nullptr, int in_elu = 0, int s2d = 0) {
         ConvGemmArgs a{};
         a.in_elu = in_elu;
+        a.s2d = s2d;
         a.x = x; a.y = y; a.w = g.w; a.wb = g.wb; a.bias = g.bias; a.res = res; a.rscale = rscale; a.y2 = post ? y2 : nullptr;
         a.xb = xb; a.yb = yb;
         a.psn_a = post ? post->ea : nullptr; a.psn_ib = post ? post->ib : nullptr;
@@ -588,7 +589,8 @@ struct PlanBuilder {
         a.Cin = g.Cin; a.N = g.N; a.NP = g.NP; a.TN = g.TN;
         a.ntaps = g.ntaps; a.shift0 = g.shift0; a.shift_step = g.step; a.S = g.S; a.pm = g.pm; a.act = act;
         int M = g.S > 1 ? (g.ntaps == 2 ? Lin - 1 : Lin) : Lin;
-        bool flat = g.ntaps == 1 && (g.S == 1 ? Lpi == Lpo : Lpo == g.S * Lpi);
+        bool flat = g.ntaps == 1 && (g.S == 1 ? Lpi == Lpo : Lpo == g.S * Lpi) && s2d <= 1;
+        if (s2d > 1) M = Lin / s2d * s2d;      // (Lpo then is the padded length of the space-to-depth tensor)
         if (flat) {
             a.units = 1; a.M = G * Lpi; a.Lin = G * Lpi; a.x_us = 0; a.y_us = 0;
         } else {

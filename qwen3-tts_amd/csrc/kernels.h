@@ -58,6 +58,9 @@ struct ConvGemmArgs {
     long x_us, x_cs, y_us, y_cs;     // unit / channel strides in floats
     int act;
     int in_elu;                      // encoder path (fp32 kernel, ENC variant): ELU(alpha=1) on the input in the staging loop
+    int s2d;                         // encoder path, > 1: store the output in space-to-depth form for a stride-s2d conv:
+                                     // element (c, m) goes to channel c*s2d + m % s2d, position m / s2d (y_cs / y_us are the
+                                     // strides of THAT tensor; M must be a multiple of s2d); the residual keeps x's strides
     int dbg;                         // timing-only ablation bits (set by the launcher from HIPVOC_DBG; 0 in production)
 };
 hipError_t launch_conv_gemm(const ConvGemmArgs &a, hipStream_t s);

@@ -327,7 +327,7 @@ __global__ __launch_bounds__(NW * 64, (FUSE && TN > 4) ? 2 : 4) void conv_gemm_k
     // epilogue: bias, activation, per-channel scale, residual, store (time on the lane: coalesced)
     float *yu = a.y + (long)unit * a.y_us;
     const float *ru0 = launder_after(a.res, acc[TN - 1][15]);
-    const float *ru = ru0 ? ru0 + (long)unit * a.y_us : nullptr;
+    const float *ru = ru0 ? ru0 + (long)unit * ((ENC && a.s2d > 1) ? a.x_us : a.y_us) : nullptr;
     float *y2u0 = launder_after(a.y2, acc[TN - 1][15]);
     float *y2u = y2u0 ? y2u0 + (long)unit * a.y_us : nullptr;
     const int m = m0 + wave * 32 + l31;
@@ -363,7 +363,9 @@ int detail::conv_gemm_launch_tn(const ConvGemmArgs &a) {
     if (a.w2 || a.wb2) return a.NP / 32;
     int tiles_m = ((a.M + BM - 1) / BM) * a.units;
     int tn = a.TN;
-    while (tn > 1 && (long)tiles_m * (a.NP / (32 * tn)) < 512) {
+    static int min_wgs = -1;
+    if (min_wgs < 0) { const char *e = getenv("HIPVOC_TN_WGS"); min_wgs = e ? atoi(e) : 384; }
+    while (tn > 1 && (long)tiles_m * (a.NP / (32 * tn)) < min_wgs) {
         int t2 = tn == 4 ? 2 : 1;
         if (a.NP % (32 * t2)) break;
         tn = t2;
@@ -379,7 +381,7 @@ const char *conv_gemm_kernel_name(const ConvGemmArgs &a) {
     static char names[3][2][8][48];
     int tn = conv_gemm_launch_tn(a);
     int fuse = a.w2 ? 1 : 0, nw = conv_gemm_waves(a);
-    const bool enc = a.in_elu || a.act == ACT_ELU || a.act == ACT_GELU_TANH;
+    const bool enc = a.in_elu || a.act == ACT_ELU || a.act == ACT_GELU_TANH || a.s2d > 1;
     char *n = names[enc ? 2 : fuse][nw == 4][tn & 7];
     if (!n[0]) snprintf(n, 48, enc ? "conv_gemm_kernel<%d,%s,%d,true>" : "conv_gemm_kernel<%d,%s,%d>", tn, fuse ? "true" : "false", nw);
     return n;
@@ -432,7 +434,8 @@ hipError_t launch_conv_gemm(const ConvGemmArgs &a_in, hipStream_t s) {
         return hipErrorInvalidValue;
     const int tn = conv_gemm_launch_tn(a);
     if (a.y2 && (!a.psn_a || !a.psn_ib || a.w2)) return hipErrorInvalidValue;
-    if ((a.in_elu || a.act == ACT_ELU || a.act == ACT_GELU_TANH) && (a.w2 || a.sn_a)) return hipErrorInvalidValue;
+    if ((a.in_elu || a.act == ACT_ELU || a.act == ACT_GELU_TANH || a.s2d > 1) && (a.w2 || a.sn_a)) return hipErrorInvalidValue;
+    if (a.s2d > 1 && (a.S != 1 || a.M % a.s2d || a.y2 || a.psn_a || a.units < 1)) return hipErrorInvalidValue;
     if (a.w2 && (a.S != 1 || a.NP != 32 * tn || (a.N + 31) / 32 != tn || tn == 5 || tn > 6 || !a.res || !a.sn2_a ||
                  !a.sn2_ib || !a.bias || !a.bias2 || ((uintptr_t)a.w2 & 15)))
         return hipErrorInvalidValue;
@@ -462,7 +465,7 @@ hipError_t launch_conv_gemm(const ConvGemmArgs &a_in, hipStream_t s) {
             default: GO(6, true);
         }
     }
-    if (a.in_elu || a.act == ACT_ELU || a.act == ACT_GELU_TANH) {
+    if (a.in_elu || a.act == ACT_ELU || a.act == ACT_GELU_TANH || a.s2d > 1) {
 #define GOE(TN_) return conv_gemm_launch_one<TN_, false, 8, true>(a, HL, XW, tiles_per_unit, n_tiles, grid, lds, s)
         switch (tn) {
             case 1: GOE(1);
