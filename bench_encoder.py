@@ -109,8 +109,18 @@ def main():
         dom = max(kernels, key=lambda nme: kernels[nme]["ms"])
         kd = kernels[dom]
         ach = kd["flops"] / (kd["ms"] * 1e-3) / 1e12
+        # HBM bytes per launch from the committed PMC passes of the same pass size (see bench.py: pmc_traffic)
+        traffic, traffic_src = None, None
+        try:
+            pj = json.load(open(os.path.join(ROOT, "profiles", "r01_encoder_pmc.json")))
+            kk = pj.get("kernels", {}).get(dom.replace(" ", ""))
+            if kk and pj.get("units_per_pass") == B:
+                traffic, traffic_src = kk["fetch_bytes_per_launch"] + kk["write_bytes_per_launch"], "profiles/r01_encoder_pmc.json"
+        except (OSError, ValueError):
+            pass
         roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "traffic_source": traffic_src,
                     "avg_launch_ms": round(kd["ms"] / kd["launches"], 4), "launches_per_pass": kd["launches"],
                     "clips_per_pass": B, "share_of_pass_time": round(kd["ms"] / sum(k["ms"] for k in kernels.values()), 3)}
         if world == 1 and not args.no_cpu:

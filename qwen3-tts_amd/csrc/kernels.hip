@@ -383,7 +383,7 @@ const char *conv_gemm_kernel_name(const ConvGemmArgs &a) {
     int fuse = a.w2 ? 1 : 0, nw = conv_gemm_waves(a);
     const bool enc = a.in_elu || a.act == ACT_ELU || a.act == ACT_GELU_TANH || a.s2d > 1;
     char *n = names[enc ? 2 : fuse][nw == 4][tn & 7];
-    if (!n[0]) snprintf(n, 48, enc ? "conv_gemm_kernel<%d,%s,%d,true>" : "conv_gemm_kernel<%d,%s,%d>", tn, fuse ? "true" : "false", nw);
+    if (!n[0]) snprintf(n, 48, "conv_gemm_kernel<%d,%s,%d,%s>", tn, fuse ? "true" : "false", nw, enc ? "true" : "false");   // as rocprofv3 prints it
     return n;
 }
 
