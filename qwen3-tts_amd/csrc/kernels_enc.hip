@@ -84,27 +84,29 @@ hipError_t launch_layernorm(const float *x, float *y, const float *w, const floa
 // BIT-EXACT CONTRACT (the encoder test oracle: linear, nearest, rvq_encode): every dot product is a k-ascending
 // fmaf chain from 0; |x|^2 and |e|^2 are k-ascending sums of ROUNDED squares; distance = (|x|^2 + |e|^2) - 2*<x,e>;
 // argmin = the first minimum.  Contraction is ruled out by spelling every operation as an intrinsic.
-// The chains fix the order along k only, so the search is a register-tiled VALU GEMM: a thread owns 8 consecutive
-// codewords x FB frames (64 independent chains); per k it loads its 8 codeword values once (transposed codebook:
-// 32 contiguous bytes per thread) and the FB residual values as two broadcast ds_read_b128.  (MFMA is not an option
+// The chains fix the order along k only, so the search is a register-tiled VALU GEMM: a thread owns 4 consecutive
+// codewords x FB frames (32 independent chains); per k it loads its 4 codeword values once (transposed codebook:
+// 16 contiguous bytes per thread) and the FB residual values as two broadcast ds_read_b128.  (MFMA is not an option
 // here: its internal summation is not an fmaf chain.)
 // ---------------------------------------------------------------------------------------------------
 static constexpr int FB = 8;    // frames per workgroup
-static constexpr int CPT = 8;   // consecutive codewords per thread
+static constexpr int CPT = 4;   // consecutive codewords per thread
+static constexpr int NT = 512;  // threads: 2048 codewords / CPT.  (256 threads x 8 codewords left 1000 equal, long-running
+                                // workgroups for 768 slots: a second round at 30 % fill; 512 threads give ~2 even rounds)
 
-__global__ __launch_bounds__(256) void rvq_encode_kernel(RvqEncArgs a) {
+__global__ __launch_bounds__(NT) void rvq_encode_kernel(RvqEncArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *hs = smem;                  // [dim][FB]
     float *xs = hs + a.dim * FB;       // [D][FB] residual
-    __shared__ float bd[FB][256];
-    __shared__ int bi[FB][256];
+    __shared__ float bd[FB][NT];
+    __shared__ int bi[FB][NT];
     __shared__ float xsq_s[FB];
     __shared__ int code_s[FB];
     const int tid = threadIdx.x;
     const long nframes = (long)a.G * a.T, f0 = (long)blockIdx.x * FB;
     const long cs = (long)a.G * a.Lp;
     const int nq = a.n_sem + a.n_ac;
-    for (int i = tid; i < a.dim * FB; i += 256) {
+    for (int i = tid; i < a.dim * FB; i += NT) {
         const int k = i / FB, f = i - k * FB;
         const long g = f0 + f;
         float v = 0.0f;
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(RvqEncArgs a) {
         const int nl = group ? a.n_ac : a.n_sem;
         if (!nl) continue;
         const float *wp = a.wp_t + (long)group * a.dim * a.D;
-        for (int d = tid; d < a.D; d += 256) {
+        for (int d = tid; d < a.D; d += NT) {
             float p[FB];
 #pragma unroll
             for (int f = 0; f < FB; f++) p[f] = 0.0f;
@@ -155,8 +157,8 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(RvqEncArgs a) {
             int besti[FB];
 #pragma unroll
             for (int f = 0; f < FB; f++) { best[f] = INFINITY; besti[f] = 0x7fffffff; }
-            const bool vec = (a.cb_size & 7) == 0;
-            for (int c0 = tid * CPT; c0 < a.cb_size; c0 += 256 * CPT) {      // ascending chunks: first minimum is kept
+            const bool vec = (a.cb_size & 3) == 0;
+            for (int c0 = tid * CPT; c0 < a.cb_size; c0 += NT * CPT) {      // ascending chunks: first minimum is kept
                 float acc[CPT][FB];
 #pragma unroll
                 for (int j = 0; j < CPT; j++)
@@ -166,8 +168,8 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(RvqEncArgs a) {
                     float e[CPT];
                     const float *ep = et + (long)d * a.cb_size + c0;
                     if (vec) {
-                        const float4 e0 = *reinterpret_cast<const float4 *>(ep), e1 = *reinterpret_cast<const float4 *>(ep + 4);
-                        e[0] = e0.x; e[1] = e0.y; e[2] = e0.z; e[3] = e0.w; e[4] = e1.x; e[5] = e1.y; e[6] = e1.z; e[7] = e1.w;
+                        const float4 e0 = *reinterpret_cast<const float4 *>(ep);
+                        e[0] = e0.x; e[1] = e0.y; e[2] = e0.z; e[3] = e0.w;
                     } else {
 #pragma unroll
                         for (int j = 0; j < CPT; j++) e[j] = c0 + j < a.cb_size ? ep[j] : 0.0f;
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(RvqEncArgs a) {
 #pragma unroll
             for (int f = 0; f < FB; f++) { bd[f][tid] = best[f]; bi[f][tid] = besti[f]; }
             __syncthreads();
-            for (int sft = 128; sft > 0; sft >>= 1) {
+            for (int sft = NT / 2; sft > 0; sft >>= 1) {
                 if (tid < sft) {
 #pragma unroll
                     for (int f = 0; f < FB; f++) {
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(RvqEncArgs a) {
                 if (g < nframes) a.codes[g * nq + q] = code;       // codes[u][t][q], frames are (u, t) flattened
             }
             __syncthreads();
-            for (int d = tid; d < a.D; d += 256)
+            for (int d = tid; d < a.D; d += NT)
 #pragma unroll
                 for (int f = 0; f < FB; f++)
                     xs[d * FB + f] = __fsub_rn(xs[d * FB + f], et[(long)d * a.cb_size + code_s[f]]);
@@ -227,7 +229,7 @@ hipError_t launch_rvq_encode(const RvqEncArgs &a, hipStream_t s) {
     size_t lds = sizeof(float) * FB * ((size_t)a.dim + a.D);
     if (lds > 40 * 1024 || a.cb_size < 1 || a.D < 1 || ((uintptr_t)a.emb_t & 15)) return hipErrorInvalidValue;
     const long nframes = (long)a.G * a.T;
-    hipLaunchKernelGGL(rvq_encode_kernel, dim3((unsigned)((nframes + FB - 1) / FB)), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(rvq_encode_kernel, dim3((unsigned)((nframes + FB - 1) / FB)), dim3(NT), lds, s, a);
     return hipGetLastError();
 }
 
