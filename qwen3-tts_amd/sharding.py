@@ -53,3 +53,22 @@ def gather_stream(local: np.ndarray, rank: int, world: int, dist=None) -> np.nda
 def shard_utterances(n_utts: int, rank: int, world: int) -> range:
     lo, hi = shard_range(n_utts, rank, world)
     return range(lo, hi)
+
+
+# ---- encoder path: clips are independent, so a batch shards as contiguous clip ranges -------------
+def encode_clips_shard(encode_batch: Callable[[Sequence[np.ndarray]], List[np.ndarray]], clips: Sequence[np.ndarray],
+                       rank: int, world: int) -> List[np.ndarray]:
+    """This rank's part of a batch of clips: its contiguous range, encoded in one pass."""
+    lo, hi = shard_range(len(clips), rank, world)
+    return list(encode_batch(clips[lo:hi])) if hi > lo else []
+
+
+def gather_codes(local: List[np.ndarray], rank: int, world: int, dist=None) -> List[np.ndarray] | None:
+    """Assemble the per-clip code arrays ([n_tokens_i, 16] int64, ragged) on rank 0 in clip order (None elsewhere)."""
+    if world == 1:
+        return local
+    parts = [None] * world if rank == 0 else None
+    dist.gather_object(local, parts, dst=0)
+    if rank != 0:
+        return None
+    return [c for p in parts for c in p]

@@ -216,3 +216,36 @@ def test_full_size_model_parity_and_device_entry_point(pkg, synth, eo):
     out = d_codes.cpu().numpy()
     assert np.array_equal(out[0], codes) and np.array_equal(out[2], codes)
     assert np.array_equal(out[1], e.encode(synth.make_audio(n, 42)))
+
+
+def test_load_and_call_errors_are_reported_not_fatal(pkg, synth, tmp_path):
+    """Error behaviour at the boundary: a bad weights file makes load return NULL with a message (the binding raises),
+    a too-small output buffer is HIPVOC_E_CAP, and the process keeps going."""
+    import ctypes as C
+    cfg = synth.ENC_ODD
+    W = dict(enc_weights_for(synth, "ENC_ODD", 0))
+    p = str(tmp_path / "bad.safetensors")
+    for victim in ("encoder.encoder.layers.3.conv.weight", "encoder.downsample.conv.weight",
+                   "encoder.quantizer.semantic_residual_vector_quantizer.input_proj.weight",
+                   "encoder.encoder_transformer.layers.0.mlp.fc2.weight"):
+        Wb = {k: v for k, v in W.items() if k != victim}
+        synth.save_safetensors(p, Wb, cfg.metadata())
+        with pytest.raises(pkg.HipVocError):
+            pkg.HipSpeechTokenizer.load(p, device=0)
+    Wb = dict(W)
+    k = "encoder.encoder.layers.1.block.3.conv.weight"
+    Wb[k] = Wb[k][:, :-1]                               # 1x1 conv whose input width no longer matches conv3's output
+    synth.save_safetensors(p, Wb, cfg.metadata())
+    with pytest.raises(pkg.HipVocError):
+        pkg.HipSpeechTokenizer.load(p, device=0)
+    with pytest.raises(pkg.HipVocError):
+        pkg.HipSpeechTokenizer.load(str(tmp_path / "missing.safetensors"), device=0)
+    with pytest.raises(pkg.HipVocError):
+        pkg.HipSpeechTokenizer.load(p, device=99)
+    e = enc_for(pkg, synth, "ENC_ODD")
+    a = synth.make_audio(1920 * 4, 2)
+    out = np.empty(3 * e.n_codebooks, dtype=np.int64)    # room for 3 frames, 4 are produced
+    n = C.c_int64(0)
+    rc = e._L.hipvoc_enc_encode(e._h, a.ctypes.data, a.size, out.ctypes.data, out.size, C.byref(n))
+    assert rc == -3 and b"capacity" in e._L.hipvoc_last_error(e._h)      # HIPVOC_E_CAP
+    assert e.encode(a).shape == (4, e.n_codebooks)
