@@ -156,3 +156,24 @@ def test_encoder_clip_sharding_world2_gloo(tmp_path):
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "OK 15" in r.stdout          # 3 + 5 + 2 + 4 + 1 frames
+
+
+def test_safetensors_reader_survives_fuzzing_under_asan_ubsan(pkg, tmp_path):
+    """tests/native/fuzz_safetensors.cpp: truncations and 20k header / length mutations of a valid file through the
+    product's reader, built with -fsanitize=address,undefined (host code only): load or fail with a message, never an
+    out-of-bounds access -- weight files come from outside."""
+    import shutil
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    rng = np.random.default_rng(0)
+    good = str(tmp_path / "good.safetensors")
+    pkg.synth.save_safetensors(good, {"a.weight": rng.standard_normal((5, 3, 2)).astype(np.float32),
+                                      "b.bias": rng.standard_normal((7,)).astype(np.float32),
+                                      "c": rng.standard_normal((2, 2)).astype(np.float32)}, {"k": "v"}, dtype="F16")
+    exe = str(tmp_path / "fuzz_st")
+    r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-o", exe,
+                        os.path.join(ROOT, "tests", "native", "fuzz_safetensors.cpp"),
+                        os.path.join(ROOT, "qwen3-tts_amd", "csrc", "safetensors.cpp")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe, good, str(tmp_path / "scratch.safetensors")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "fuzz_safetensors OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -123,3 +123,22 @@ def test_vocode_batch_round_trip(wire):
 def test_framing_constants(wire):
     assert wire.MAX_MESSAGE == 100_000_000                       # src/worker/mod.rs:666
     assert struct.pack(">I", 5) == b"\x00\x00\x00\x05"          # u32 big-endian length (worker_client.rs:34-35)
+
+
+def test_wire_codec_survives_fuzzing_under_asan_ubsan(tmp_path):
+    """tests/native/fuzz_wire.cpp: truncations and ~200k mutations of valid requests plus noise through both parsers
+    and the encoders, built with -fsanitize=address,undefined (host code only; the worker feeds these parsers bytes
+    straight from a socket)."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    exe = str(tmp_path / "fuzz_wire")
+    r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-o", exe,
+                        os.path.join(root, "tests", "native", "fuzz_wire.cpp"),
+                        os.path.join(root, "qwen3-tts_amd", "csrc", "wire.cpp")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "fuzz_wire OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
