@@ -43,21 +43,14 @@ struct EncModel {
     }
 };
 
-static std::map<Ctx *, std::unique_ptr<EncModel>> g_enc;      // encoder state of a handle (guarded by g_err_mu)
-
 static void enc_release(Ctx *c) {
-    std::lock_guard<std::mutex> lk(g_err_mu);
-    auto it = g_enc.find(c);
-    if (it == g_enc.end()) return;
-    if (it->second->d_codes) (void)hipFree(it->second->d_codes);
-    g_enc.erase(it);
+    if (!c->enc) return;
+    if (c->enc->d_codes) (void)hipFree(c->enc->d_codes);
+    delete c->enc;
+    c->enc = nullptr;
 }
 
-static EncModel *enc_of(Ctx *c) {
-    std::lock_guard<std::mutex> lk(g_err_mu);
-    auto it = g_enc.find(c);
-    return it == g_enc.end() ? nullptr : it->second.get();
-}
+static EncModel *enc_of(Ctx *c) { return c->enc; }
 
 // CausalConv1d with kernel 2r and stride r as a 2-tap GEMM over the space-to-depth input:
 // out[co][q] = sum_{tap,ci,j} W[co][ci][tap*r + j] * x[ci][(q - 1 + tap)*r + j]   (left pad r = one whole block)
@@ -441,10 +434,7 @@ void *hipvoc_enc_load(const char *weights_path, int device_id) {
     std::string err;
     if (!enc_load_model(c.get(), m.get(), weights_path, err)) return fail(err);
     if (hipDeviceSynchronize() != hipSuccess) return fail("device error after load");
-    {
-        std::lock_guard<std::mutex> lk(g_err_mu);
-        g_enc[c.get()] = std::move(m);
-    }
+    c->enc = m.release();
     return c.release();
 }
 

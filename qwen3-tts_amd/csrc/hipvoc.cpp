@@ -92,8 +92,11 @@ struct Plan {
     float *enc_audio = nullptr;    // encoder plans: the input buffer this plan's first step reads
 };
 
+struct EncModel;      // encoder.inc.cpp
+
 struct Ctx {
     int device = 0;
+    EncModel *enc = nullptr;   // set on handles made by hipvoc_enc_load; owned (enc_release)
     int unit_frames = 64;
     int group = 64;
     bool profile = false;
