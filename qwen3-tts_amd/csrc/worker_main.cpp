@@ -26,6 +26,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <future>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -246,22 +247,84 @@ static std::vector<uint8_t> handle(const std::vector<uint8_t> &msg) {
     return simple(0, "Init", "Read: Deserialize request failed: malformed message");
 }
 
+// One connection.  The reference's orchestrator PIPELINES vocoder requests on its connection (pipeline.rs:586-607 sends a
+// Vocode per 64-token chunk while the talker is still generating, 651 queues the tail, 660-672 then reads the responses
+// in submission order), so this thread only reads and dispatches frames; up to MAX_INFLIGHT requests of the connection
+// are decoded concurrently -- they meet in the GPU queue and leave as one batched pass -- and a writer thread returns
+// the responses in order.
+static const size_t MAX_INFLIGHT = 8;
+
 static void client(int fd) {
     int one = 1;
     setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
-    std::vector<uint8_t> msg;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::future<std::vector<uint8_t>>> inflight;
+    bool eof = false, broken = false;
+    std::thread writer([&] {
+        for (;;) {
+            std::future<std::vector<uint8_t>> f;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return !inflight.empty() || eof; });
+                if (inflight.empty()) return;
+                f = std::move(inflight.front());
+            }
+            std::vector<uint8_t> resp = f.get();
+            bool ok = send_frame(fd, resp);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                inflight.pop_front();                       // (popped after the send: the reader's bound counts it)
+                if (!ok) broken = true;
+            }
+            cv.notify_all();
+            if (!ok) {                                      // peer gone: drain what is still running, send nothing
+                for (;;) {
+                    std::future<std::vector<uint8_t>> g;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [&] { return !inflight.empty() || eof; });
+                        if (inflight.empty()) return;
+                        g = std::move(inflight.front());
+                        inflight.pop_front();
+                    }
+                    g.get();
+                    cv.notify_all();
+                }
+            }
+        }
+    });
     for (;;) {
         uint8_t lb[4];
         if (!read_all(fd, lb, 4)) break;                       // client went away (mod.rs:662-664)
         size_t len = ((size_t)lb[0] << 24) | ((size_t)lb[1] << 16) | ((size_t)lb[2] << 8) | lb[3];
+        std::future<std::vector<uint8_t>> fut;
+        bool last = false;
         if (len > MAX_MSG) {                                   // mod.rs:666-668, 603-611: error response, then close
-            send_frame(fd, simple(0, "Init", "Read: Message too large"));
-            break;
+            std::promise<std::vector<uint8_t>> pr;
+            pr.set_value(simple(0, "Init", "Read: Message too large"));
+            fut = pr.get_future();
+            last = true;
+        } else {
+            std::vector<uint8_t> msg(len);
+            if (len && !read_all(fd, msg.data(), len)) break;
+            fut = std::async(std::launch::async, [m = std::move(msg)] { return handle(m); });
         }
-        msg.resize(len);
-        if (len && !read_all(fd, msg.data(), len)) break;
-        if (!send_frame(fd, handle(msg))) break;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return inflight.size() < MAX_INFLIGHT || broken; });
+            inflight.push_back(std::move(fut));
+            if (broken) last = true;
+        }
+        cv.notify_all();
+        if (last) break;
     }
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        eof = true;
+    }
+    cv.notify_all();
+    writer.join();
     close(fd);
 }
 

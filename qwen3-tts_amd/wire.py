@@ -196,3 +196,30 @@ class WorkerClient:
         out = [np.frombuffer(bytes(a), dtype="<i2") for a in audio]
         assert [o.size for o in out] == list(n_samples)
         return out
+
+    def vocode_streamed(self, codes: np.ndarray, chunk_size: int = 64) -> np.ndarray:
+        """The orchestrator's vocoder phase (src/pipeline.rs:586-607, 636-673): one Vocode request per full
+        ``chunk_size`` tokens is SENT as soon as the tokens exist, the remainder is queued last, and only then are the
+        responses read, in submission order, and their samples concatenated -- several requests are in flight on the
+        connection at once."""
+        codes = np.ascontiguousarray(codes, dtype=np.int64).reshape(-1, 16)
+        n = codes.shape[0]
+        sent = 0
+        pending = 0
+        while n - sent >= chunk_size:                       # "send partial batch when we have enough tokens"
+            self.send_raw(request_vocode(codes[sent: sent + chunk_size]))
+            sent += chunk_size
+            pending += 1
+        if sent < n:                                        # "queue remaining tail"
+            self.send_raw(request_vocode(codes[sent:]))
+            pending += 1
+        parts = []
+        for _ in range(pending):                            # "collect responses in submission order"
+            status, data, err = self.read_response()
+            if status != "ok":
+                raise WorkerError(err or "unknown")
+            audio, n_samples = data["Vocode"]
+            pcm = np.frombuffer(bytes(audio), dtype="<i2")
+            assert pcm.size == n_samples
+            parts.append(pcm)
+        return np.concatenate(parts) if parts else np.zeros(0, dtype=np.int16)

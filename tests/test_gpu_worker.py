@@ -162,3 +162,32 @@ def test_worker_decodes_a_voice_profile_file(pkg, synth, vo, worker, tmp_path):
     ref = oracle_for(vo, synth, "SMALL", 0).synthesize(codes, 4)
     assert pcm.size == ref.size
     assert np.abs(pcm.astype(np.int32) - vo.pcm16(ref).astype(np.int32)).max() <= 33
+
+
+def test_worker_serves_the_orchestrators_pipelined_requests_in_order(pkg, synth, worker):
+    """src/pipeline.rs:586-673 keeps several Vocode requests in flight on ONE connection and reads the responses in
+    submission order.  The worker decodes them concurrently (they share a batched pass) and must answer in order, with
+    exactly the bytes of one-at-a-time calls; an error in the middle stays in its slot."""
+    wire = pkg.wire
+    cfg = synth.SMALL
+    codes = synth.make_codes(23, 321, cfg)                  # chunk 4 -> 5 full requests + a 3-token tail, all in flight
+    c = wire.WorkerClient("127.0.0.1", worker)
+    got = c.vocode_streamed(codes, chunk_size=4)
+    c2 = wire.WorkerClient("127.0.0.1", worker)
+    want = np.concatenate([c2.vocode(codes[s: s + 4]) for s in range(0, 23, 4)])
+    assert got.size == 5 * cfg.out_len(4) + 3 * 1920 and np.array_equal(got, want)      # full units lose the 555-sample trim
+    # 12 requests at once (more than the worker keeps in flight per connection), the 6th is invalid
+    reqs = [synth.make_codes(2 + i % 3, 400 + i, cfg) for i in range(12)]
+    bad = reqs[5].copy()
+    bad[0, 0] = cfg.codebook_size + 7
+    for i, r in enumerate(reqs):
+        c.send_raw(wire.request_vocode(bad if i == 5 else r))
+    for i, r in enumerate(reqs):
+        status, data, err = c.read_response()
+        if i == 5:
+            assert status == "error" and "code" in err
+            continue
+        assert status == "ok"
+        pcm = np.frombuffer(bytes(data["Vocode"][0]), dtype="<i2")
+        assert np.array_equal(pcm, c2.vocode(r)), i
+    assert c.ping()
