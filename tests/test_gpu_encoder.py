@@ -249,3 +249,38 @@ def test_load_and_call_errors_are_reported_not_fatal(pkg, synth, tmp_path):
     rc = e._L.hipvoc_enc_encode(e._h, a.ctypes.data, a.size, out.ctypes.data, out.size, C.byref(n))
     assert rc == -3 and b"capacity" in e._L.hipvoc_last_error(e._h)      # HIPVOC_E_CAP
     assert e.encode(a).shape == (4, e.n_codebooks)
+
+
+def test_full_size_batch_properties(pkg, synth):
+    """The bench's workload shape (many 10 s clips in one device-resident pass, full-size model), checked through
+    size-independent properties: every clip's codes equal encoding that clip alone (host path), a clip's prefix
+    encodes to the prefix of its codes (causality), and a second pass is bit-identical (determinism)."""
+    import torch
+    cfg = synth.ENC_FULL
+    path = os.path.join(tempfile.gettempdir(), "hipenc_test_ENC_FULL_0.safetensors")
+    if not os.path.exists(path):
+        synth.save_safetensors(path, enc_weights_for(synth, "ENC_FULL", 0), cfg.metadata())
+    e = pkg.HipSpeechTokenizer.load(path, device=0)
+    B, n = 24, 24000 * 10
+    base = [synth.make_audio(n, 700 + i) for i in range(4)]
+    audio = np.stack([base[i % 4] for i in range(B)])
+    d_audio = torch.from_numpy(audio).cuda()
+    T = e.n_frames(n)
+    assert T == 125
+    d_codes = torch.empty((B, T, 16), dtype=torch.int64, device="cuda")
+    e.encode_device(d_audio.data_ptr(), B, n, n, d_codes.data_ptr())
+    e.sync()
+    first = d_codes.cpu().numpy()
+    assert first.min() >= 0 and first.max() < cfg.codebook_size
+    for i in range(4):
+        alone = e.encode(base[i])
+        for j in range(i, B, 4):
+            assert np.array_equal(first[j], alone), (i, j)
+    assert np.array_equal(e.encode(base[1][: 1920 * 40 + 123]), first[1][:40])
+    d_codes.zero_()
+    e.encode_device(d_audio.data_ptr(), B, n, n, d_codes.data_ptr())
+    e.sync()
+    assert np.array_equal(d_codes.cpu().numpy(), first)
+    # codes are not degenerate: many distinct entries of every codebook are used across the batch
+    for q in (0, 1, 15):
+        assert np.unique(first[:4, :, q]).size > 50
