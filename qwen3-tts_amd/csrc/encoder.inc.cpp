@@ -247,6 +247,10 @@ static Plan *enc_get_plan(Ctx *c, EncModel *m, int G, long n, bool debug) {
     auto key = std::make_pair(debug ? -G : G, n);
     auto it = m->plans.find(key);
     if (it != m->plans.end()) return it->second.get();
+    // one plan per (batch, length): a service that sees arbitrary clip lengths must not grow this without bound.  A plan
+    // is only host-side launch closures (its launches are already enqueued when a later call gets here), so dropping
+    // the cache is safe; the workspace buffers stay.
+    if (m->plans.size() >= 128) m->plans.clear();
     std::unique_ptr<Plan> plan(new Plan);
     plan->G = G; plan->T = (int)m->n_frames(n);
     PlanBuilder b{c, plan.get(), G, plan->T};
@@ -375,7 +379,8 @@ static int enc_run(Ctx *c, EncModel *m, const float *const *audio, const int64_t
         n = std::max<long>(n, (long)n_samples[i]);
     }
     if (m->n_frames(n) < 1) { c->err = fmt("audio too short: %ld samples give no frame (one frame = %d samples)", n, m->samples_per_frame()); return HIPVOC_E_ARG; }
-    if (n > 0x7ffffff0L / 4) { c->err = "audio too long for one pass"; return HIPVOC_E_ARG; }
+    // the kernels index positions of one tensor row-set with 32-bit ints (flat 1x1 convs see B * padded length columns)
+    if (n > 0x7ffffff0L / 4 || (long)B * rupl(n, 4) > 0x7fffff00L) { c->err = "batch too long for one pass: split it"; return HIPVOC_E_ARG; }
     Plan *p = enc_get_plan(c, m, B, n, stop_stage >= 0);
     if (!p) { if (c->err.empty()) c->err = "workspace allocation failed"; return HIPVOC_E_HIP; }
     const int Lp0 = (int)rupl(n, 4);
