@@ -102,7 +102,7 @@ struct Ctx {
     bool profile = false;
     bool fuse_res = true;
     bool post_snake = true;
-    bool phase_major = true;   // bf16 mode: transposed-conv rows phase-major (HIPVOC_PHASE_MAJOR=0: channel-major)
+    bool phase_major = true;   // transposed-conv rows phase-major (HIPVOC_PHASE_MAJOR=0: channel-major)
     bool packed = true;        // bf16 mode: GEMM-to-GEMM tensors of the decoder stack exchanged as packed bf16 (HIPVOC_PACKED=0: fp32)
     bool is_encoder = false;   // handle made by hipvoc_enc_load (encoder.inc.cpp): the vocoder entry points refuse it
     bool bf16 = false;         // HIPVOC_DTYPE_BF16: conv-GEMM operands in bf16, fp32 accumulate, everything else fp32
@@ -350,9 +350,10 @@ struct Loader {
         int Cin = (int)sh[0], Co = (int)sh[1], K = (int)sh[2];
         g.Cin = Cin; g.N = Co * s; g.TN = pick_tn(g.N); g.NP = rup(g.N, 32 * g.TN);
         g.ntaps = K / s; g.shift0 = 0; g.step = 1; g.S = s;
-        // bf16 mode: phase-major rows, so that a lane's four consecutive accumulator rows are four channels of one
-        // output position (8-byte stores into the packed bf16 tensors instead of four 2-byte ones)
-        g.pm = c->bf16 && c->phase_major && s > 1 && Co % 8 == 0;
+        // phase-major rows: a lane's four consecutive accumulator rows are four channels of one output position (bf16
+        // mode: 8-byte stores into the packed tensors instead of four 2-byte ones; both modes: one integer division
+        // per half tile in the epilogue instead of one per row)
+        g.pm = c->phase_major && s > 1 && Co % 8 == 0;
         int CinP = rup(Cin, 32);
         std::vector<float> p((size_t)g.ntaps * CinP * g.NP, 0.0f);
         for (int ci = 0; ci < Cin; ci++)
