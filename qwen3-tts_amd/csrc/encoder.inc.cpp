@@ -18,6 +18,7 @@ namespace hipvoc {
 struct EncModel {
     int n_filters = 0, dim = 0, n_layers = 0, ff = 0, n_heads = 8, context = 250, n_use = 16, ds_stride = 2;
     float rope_max_period = 10000.f, ln_eps = 1e-5f;
+    int conv0_taps = 7;
     int cb_size = 0, D = 0, n_sem = 0, n_ac = 0;      // n_sem / n_ac: layers actually evaluated (the first n_use)
     Gemm conv0, fin, ds;
     struct Blk { Gemm c1, c2, down; int C = 0, ratio = 0; };
@@ -84,6 +85,29 @@ static Gemm enc_conv(Loader &L, const std::string &prefix, int dil = 1) {
     return L.conv({prefix + ".weight"}, L.st.has(b) ? b : std::string(), dil);     // bias is optional (speech_tokenizer.rs:56)
 }
 
+// The first conv (1 input channel, K taps, causal): W'[j][co] = W[co][0][j] over the K shifted copies of the waveform.
+static Gemm enc_conv0(Loader &L, const std::string &prefix) {
+    Gemm g;
+    std::vector<float> w;
+    std::vector<int64_t> sh;
+    if (!L.get(prefix + ".weight", w, sh)) return g;
+    if (sh.size() != 3 || sh[1] != 1) {
+        L.err = prefix + ".weight: expected [C, 1, K]";
+        L.ok = false;
+        return g;
+    }
+    const int Co = (int)sh[0], K = (int)sh[2];
+    g.Cin = K; g.N = Co; g.TN = pick_tn(Co); g.NP = rup(Co, 32 * g.TN);
+    g.ntaps = 1; g.shift0 = 0; g.step = 0; g.S = 1;
+    const int CinP = rup(K, 32);
+    std::vector<float> p((size_t)CinP * g.NP, 0.0f);
+    for (int co = 0; co < Co; co++)
+        for (int j = 0; j < K; j++) p[(size_t)j * g.NP + co] = w[(size_t)co * K + j];
+    L.finish(g, p, CinP);
+    if (L.st.has(prefix + ".bias")) g.bias = L.vec(prefix + ".bias", Co);
+    return g;
+}
+
 static bool enc_load_model(Ctx *c, EncModel *m, const char *path, std::string &err) {
     Loader L;
     L.c = c;
@@ -98,7 +122,8 @@ static bool enc_load_model(Ctx *c, EncModel *m, const char *path, std::string &e
     const StTensor *w0 = L.st.find(E + "0.conv.weight");
     if (!w0 || w0->shape.size() != 3 || w0->shape[1] != 1) { err = "missing/invalid " + E + "0.conv.weight"; return false; }
     m->n_filters = (int)w0->shape[0];
-    m->conv0 = enc_conv(L, E + "0.conv");
+    m->conv0 = enc_conv0(L, E + "0.conv");      // 1-tap GEMM over the tap stack of the waveform (launch_tap_stack)
+    m->conv0_taps = (int)w0->shape[2];
     int idx = 1, C = m->n_filters;
     while (L.st.has(E + fmt("%d.block.1.conv.weight", idx))) {       // SEANetEncoder::load 187-215
         EncModel::Blk b;
@@ -200,7 +225,7 @@ static bool enc_load_model(Ctx *c, EncModel *m, const char *path, std::string &e
     // algorithmic MACs per input sample (for throughput lines)
     {
         double macs = 0, rate = 1.0;
-        macs += (double)m->conv0.N * m->conv0.Cin * m->conv0.ntaps;
+        macs += (double)m->conv0.N * m->conv0.Cin * m->conv0.ntaps;      // (Cin = taps here)
         for (const EncModel::Blk &b : m->blocks) {
             macs += rate * ((double)b.c1.N * b.c1.Cin * b.c1.ntaps + (double)b.c2.N * b.c2.Cin);
             rate /= b.ratio;
@@ -258,7 +283,7 @@ static Plan *enc_get_plan(Ctx *c, EncModel *m, int G, long n, bool debug) {
     size_t big = 0, sd = 0, mid = 0;
     {
         long L = n;
-        big = (size_t)m->n_filters * rupl(L, 4);
+        big = (size_t)std::max(m->n_filters, m->conv0_taps) * rupl(L, 4);      // (the tap stack lives in a ping-pong buffer)
         for (const EncModel::Blk &bl : m->blocks) {
             mid = std::max(mid, (size_t)bl.c1.N * rupl(L, 4));
             long Lq = L / bl.ratio;
@@ -282,7 +307,14 @@ static Plan *enc_get_plan(Ctx *c, EncModel *m, int G, long n, bool debug) {
     int st = 0;
     int L = (int)n, Lp = Lp0;
     float *h = A, *o = B;
-    b.gemm("enc_conv0", m->conv0, audio, L, Lp, h, Lp, nullptr, nullptr, nullptr, ACT_NONE);
+    {
+        // taps of the waveform as channels (into the other ping-pong buffer), then the first conv as a 1-tap GEMM
+        const float *x = audio;
+        float *y = o;
+        const int K = m->conv0_taps, GG = G, LL = L, LLp = Lp;
+        b.add("enc_tap_stack", "tap_stack_kernel", 0, [=](hipStream_t s) { return launch_tap_stack(x, y, K, GG, LL, LLp, s); });
+    }
+    b.gemm("enc_conv0", m->conv0, o, L, Lp, h, Lp, nullptr, nullptr, nullptr, ACT_NONE);
     b.mark(st++, h, m->conv0.N, L, Lp);
     for (const EncModel::Blk &bl : m->blocks) {
         // ResidualBlock::forward (139-149); ELU is applied where the value is consumed / produced

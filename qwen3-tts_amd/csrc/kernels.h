@@ -114,6 +114,8 @@ hipError_t launch_pcm16(const float *x, int16_t *y, long n, hipStream_t s);
 // y[(c*r + j)][u][q] = act(x[c][u][q*r + j]) for q < L / r: the space-to-depth form in which a conv of kernel 2r and
 // stride r (CausalConv1d with pad k - s = r) is a 2-tap conv over c*r channels.  elu: apply ELU(alpha=1) first.
 hipError_t launch_s2d(const float *x, float *y, int C, int G, int L, int Lp, int r, int Lq, int Lqp, int elu, hipStream_t s);
+// y[j][u][t] = x[u][t + j - (K-1)] (0 before the start): the taps of a single-channel causal conv as K channels
+hipError_t launch_tap_stack(const float *x, float *y, int K, int G, int L, int Lp, hipStream_t s);
 // LayerNorm with bias over channels of x[C][P] (speech_tokenizer.rs:394-403): biased variance, eps inside the sqrt
 hipError_t launch_layernorm(const float *x, float *y, const float *w, const float *b, int C, long P, float eps, hipStream_t s);
 struct RvqEncArgs {

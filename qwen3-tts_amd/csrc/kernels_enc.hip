@@ -36,6 +36,29 @@ hipError_t launch_s2d(const float *x, float *y, int C, int G, int L, int Lp, int
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Tap stack of a single-channel signal: y[j][u][t] = x[u][t + j - (K-1)] (0 before the start), j < K.  The encoder's
+// first conv (1 -> 64 channels, K = 7, causal) is then a 1-tap GEMM over K "channels": one K stage instead of K stages
+// whose 16-channel blocks hold one real channel each.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tap_stack_kernel(const float *x, float *y, int K, int G, int L, int Lp) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int u = blockIdx.y;
+    if (t >= L) return;
+    const float *xr = x + (long)u * Lp;
+    for (int j = 0; j < K; j++) {
+        const int sidx = t + j - (K - 1);
+        y[((long)j * G + u) * Lp + t] = sidx >= 0 ? xr[sidx] : 0.0f;
+    }
+}
+
+hipError_t launch_tap_stack(const float *x, float *y, int K, int G, int L, int Lp, hipStream_t s) {
+    if (G <= 0 || L <= 0) return hipSuccess;
+    if (K < 1 || G > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(tap_stack_kernel, dim3((L + 255) / 256, G), dim3(256), 0, s, x, y, K, G, L, Lp);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
 // LayerNorm with bias over channels of x[C][P] (speech_tokenizer.rs:394-403): mean, biased variance of the centred
 // values, (x - mean) / sqrt(var + eps) * w + b.  Workgroup = 32 positions x 8 channel slices, slices reduced through
 // LDS in a fixed order (same shape as rmsnorm_kernel).
