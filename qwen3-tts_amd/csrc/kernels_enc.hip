@@ -112,7 +112,10 @@ hipError_t launch_layernorm(const float *x, float *y, const float *w, const floa
 // 16 contiguous bytes per thread) and the FB residual values as two broadcast ds_read_b128.  (MFMA is not an option
 // here: its internal summation is not an fmaf chain.)
 // ---------------------------------------------------------------------------------------------------
-static constexpr int FB = 8;    // frames per workgroup
+#ifndef HIPVOC_RVQ_FB
+#define HIPVOC_RVQ_FB 8
+#endif
+static constexpr int FB = HIPVOC_RVQ_FB;    // frames per workgroup
 static constexpr int CPT = 4;   // consecutive codewords per thread
 static constexpr int NT = 512;  // threads: 2048 codewords / CPT.  (256 threads x 8 codewords left 1000 equal, long-running
                                 // workgroups for 768 slots: a second round at 30 % fill; 512 threads give ~2 even rounds)
@@ -150,8 +153,12 @@ __global__ __launch_bounds__(NT) void rvq_encode_kernel(RvqEncArgs a) {
             for (int f = 0; f < FB; f++) p[f] = 0.0f;
             for (int k = 0; k < a.dim; k++) {
                 const float w = wp[(long)k * a.D + d];
-                const float4 x0 = *reinterpret_cast<const float4 *>(hs + k * FB), x1 = *reinterpret_cast<const float4 *>(hs + k * FB + 4);
-                const float xv[FB] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                float xv[FB];
+#pragma unroll
+                for (int f4 = 0; f4 < FB / 4; f4++) {
+                    const float4 x4 = *reinterpret_cast<const float4 *>(hs + k * FB + 4 * f4);
+                    xv[4 * f4] = x4.x; xv[4 * f4 + 1] = x4.y; xv[4 * f4 + 2] = x4.z; xv[4 * f4 + 3] = x4.w;
+                }
 #pragma unroll
                 for (int f = 0; f < FB; f++) p[f] = __builtin_fmaf(w, xv[f], p[f]);
             }
@@ -197,8 +204,12 @@ __global__ __launch_bounds__(NT) void rvq_encode_kernel(RvqEncArgs a) {
 #pragma unroll
                         for (int j = 0; j < CPT; j++) e[j] = c0 + j < a.cb_size ? ep[j] : 0.0f;
                     }
-                    const float4 x0 = *reinterpret_cast<const float4 *>(xs + d * FB), x1 = *reinterpret_cast<const float4 *>(xs + d * FB + 4);
-                    const float xv[FB] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                    float xv[FB];
+#pragma unroll
+                    for (int f4 = 0; f4 < FB / 4; f4++) {
+                        const float4 x4 = *reinterpret_cast<const float4 *>(xs + d * FB + 4 * f4);
+                        xv[4 * f4] = x4.x; xv[4 * f4 + 1] = x4.y; xv[4 * f4 + 2] = x4.z; xv[4 * f4 + 3] = x4.w;
+                    }
 #pragma unroll
                     for (int j = 0; j < CPT; j++)
 #pragma unroll
@@ -250,7 +261,7 @@ __global__ __launch_bounds__(NT) void rvq_encode_kernel(RvqEncArgs a) {
 hipError_t launch_rvq_encode(const RvqEncArgs &a, hipStream_t s) {
     if (a.G <= 0 || a.T <= 0) return hipSuccess;
     size_t lds = sizeof(float) * FB * ((size_t)a.dim + a.D);
-    if (lds > 40 * 1024 || a.cb_size < 1 || a.D < 1 || ((uintptr_t)a.emb_t & 15)) return hipErrorInvalidValue;
+    if (lds > 64 * 1024 || a.cb_size < 1 || a.D < 1 || ((uintptr_t)a.emb_t & 15)) return hipErrorInvalidValue;
     const long nframes = (long)a.G * a.T;
     hipLaunchKernelGGL(rvq_encode_kernel, dim3((unsigned)((nframes + FB - 1) / FB)), dim3(NT), lds, s, a);
     return hipGetLastError();
