@@ -25,7 +25,7 @@ def worker(synth):
     p = subprocess.Popen([exe, "-r", "vocoder", "-m", path, "-b", "127.0.0.1:0", "--unit-frames", "4"],
                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     line = p.stdout.readline()
-    assert "listening on" in line, line + p.stdout.read()
+    assert "listening on" in line and "2 device handle(s)" in line, line + p.stdout.read()      # default: two contexts on the GPU
     port = int(line.split("listening on ")[1].split()[0].rsplit(":", 1)[1])
     yield port
     p.kill()
@@ -94,7 +94,7 @@ def test_worker_batches_across_connections_on_two_handles(pkg, synth, worker):
     cfg = synth.SMALL
     path = os.path.join(tempfile.gettempdir(), "hipvoc_test_SMALL_0.safetensors")
     exe = os.path.join(ROOT, "qwen3-tts_amd", "hipvoc-worker")
-    p = subprocess.Popen([exe, "-m", path, "-b", "127.0.0.1:0", "--unit-frames", "4", "--devices", "0,0"],
+    p = subprocess.Popen([exe, "-m", path, "-b", "127.0.0.1:0", "--unit-frames", "4", "--devices", "0,0", "--contexts", "1"],
                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     try:
         line = p.stdout.readline()
