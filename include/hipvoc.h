@@ -46,7 +46,10 @@ int hipvoc_device_count(void);
  * weights_path: a .safetensors file holding the upstream `decoder.*` tensors of the Qwen3-TTS
  * speech tokenizer (F32/F16/BF16); architecture is derived from tensor shapes, the few
  * hyper-parameters shapes cannot tell come from the file's __metadata__ (defaults: 16 heads,
- * window 72, rope theta 1e4, rms eps 1e-5).
+ * window 72, rope theta 1e4, rms eps 1e-5; keys num_attention_heads, sliding_window, rope_theta, rms_norm_eps).
+ * transconv_trim_right_only=1 selects the other trim policy of the decoder blocks' transposed convs: k - s samples off
+ * the right only (exactly 1920 samples per frame) instead of off both sides (1920*T - 555 per unit, the default, which
+ * follows the published sibling decoder).  Which one the reference's shipped vocoder.onnx has cannot be read offline.
  * unit_frames: frames per decode unit = the reference's `max_tokens` (ONNX input dim 1; 64).
  * Returns NULL on failure; hipvoc_last_error(NULL) then holds the reason.
  */

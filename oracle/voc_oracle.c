@@ -28,7 +28,7 @@
  * PARITY STATUS: the reference holds no golden vectors for this path and its arithmetic (ONNX
  * Runtime + vocoder.onnx) is absent offline, so parity against the shipped ONNX graph is
  * UNPINNED.  This restatement IS pinned against the transformers building blocks listed above
- * (tests/golden/make_golden.py generated tests/golden/*.npz from them with seeded weights;
+ * (tests/golden/make_golden.py generated the tests/golden .npz fixtures from them with seeded weights;
  * tests/test_oracle_golden.py checks this file against those fixtures).
  *
  * Layout: every activation is channel-first [C][L] row-major (PyTorch NCL with N=1).
@@ -62,6 +62,7 @@ typedef struct VocOracle {
      * transposed conv with more than one output channel are rounded to bf16 (nearest even), products and sums
      * stay fp32.  0 (default): the reference's fp32 arithmetic. */
     int bf16_gemm;
+    int trim_right_only; /* trans-conv trim policy, see transconv_causal (default 0 = both sides) */
     /* derived */
     int finalized;
     int n_q, cb_size, cb_dim, q_out, latent, hidden, n_layers, qkv_dim, head_dim, inter;
@@ -95,6 +96,7 @@ int voc_oracle_set_param(VocOracle *o, const char *name, double v) {
     else if (!strcmp(name, "rope_theta")) o->rope_theta = (float)v;
     else if (!strcmp(name, "rms_norm_eps")) o->rms_eps = (float)v;
     else if (!strcmp(name, "bf16_gemm")) o->bf16_gemm = v != 0;
+    else if (!strcmp(name, "transconv_trim_right_only")) o->trim_right_only = v != 0;
     else return -1;
     return 0;
 }
@@ -205,11 +207,12 @@ int voc_oracle_finalize(VocOracle *o) {
     return o->err[0] ? -1 : 0;
 }
 
-/* frames -> samples: every trans-conv with k=2r,s=r trims r on both sides (TF:3221-3228) */
+/* frames -> samples: every trans-conv with k=2r,s=r trims r on both sides (TF:3221-3228): (L-1)*r; with the
+ * right-only policy (see transconv_causal) it keeps L*r */
 int64_t voc_oracle_out_len(const VocOracle *o, int T) {
     int64_t L = T;
     for (int i = 0; i < o->n_up; i++) L *= o->up_ratio[i];
-    for (int i = 0; i < o->n_blocks; i++) L = (L - 1) * o->rates[i];
+    for (int i = 0; i < o->n_blocks; i++) L = o->trim_right_only ? L * o->rates[i] : (L - 1) * o->rates[i];
     return L;
 }
 
@@ -310,16 +313,22 @@ static void dwconv_causal(const float *x, int C, int64_t L, const float *w, cons
         }
 }
 
-/* ConvTranspose1d(k, stride s) + trim pad=k-s on both sides (TF:3216-3228).  w[Cin][Cout][K].
- * full[co][i*s+j] = b[co] + sum_ci x[ci][i]*w[ci][co][j];  y = full[:, pad : Lfull-pad]. */
-static int64_t transconv_len(int64_t L, int K, int s) { return (L - 1) * s + K - 2 * (K - s); }
+/* ConvTranspose1d(k, stride s) + trim of pad = k - s samples.  w[Cin][Cout][K].
+ * full[co][i*s+j] = b[co] + sum_ci x[ci][i]*w[ci][co][j]
+ * Trim policy (which one the shipped vocoder.onnx has cannot be verified offline, so it is a switch):
+ *   both sides (default; the sibling Qwen3OmniMoeCausalTransConvNet, TF:3216-3228): y = full[:, pad : Lfull - pad],
+ *     length (L-1)*s -- hence 1920*T - 555 samples per unit;
+ *   right only (`transconv_trim_right_only`; Mimi's causal MimiConvTranspose1d with trim_right_ratio = 1,
+ *     TF:models/mimi/modeling_mimi.py): y = full[:, 0 : Lfull - pad], length L*s -- exactly 1920*T samples per unit. */
+static int g_trim_right = 0; /* set from o->trim_right_only on entry of decoder_forward */
+static int64_t transconv_len(int64_t L, int K, int s) { return g_trim_right ? (L - 1) * s + K - (K - s) : (L - 1) * s + K - 2 * (K - s); }
 
 static void transconv_causal(const float *x_in, int Cin, int64_t L, const float *w_in, const float *b, int Cout, int K,
                              int s, float *y) {
     float *xr = g_bf16 ? bf16_copy(x_in, (int64_t)Cin * L) : NULL, *wr = g_bf16 ? bf16_copy(w_in, (int64_t)Cin * Cout * K) : NULL;
     const float *x = xr ? xr : x_in, *w = wr ? wr : w_in;
     int pad = K - s;
-    int64_t Lf = (L - 1) * s + K, Lo = Lf - 2 * pad;
+    int64_t Lf = (L - 1) * s + K, Lo = g_trim_right ? Lf - pad : Lf - 2 * pad;
 #pragma omp parallel
     {
         float *full = (float *)malloc(sizeof(float) * Lf);
@@ -337,7 +346,7 @@ static void transconv_causal(const float *x_in, int Cin, int64_t L, const float 
                 }
                 for (int64_t i = 0; i < L; i++) full[i * s + j] += tmp[i];
             }
-            memcpy(y + (int64_t)co * Lo, full + pad, sizeof(float) * Lo);
+            memcpy(y + (int64_t)co * Lo, full + (g_trim_right ? 0 : pad), sizeof(float) * Lo);
         }
         free(full);
         free(tmp);
@@ -540,6 +549,7 @@ static int decoder_forward(VocOracle *o, const int64_t *codes, int T, float *wav
     if (T < 1 || T > 4096) { snprintf(o->err, sizeof o->err, "bad T"); return -1; }
     o->err[0] = 0;
     g_bf16 = o->bf16_gemm;
+    g_trim_right = o->trim_right_only;
     int st = 0;
     /* g1: RVQ */
     float *sums = (float *)malloc(sizeof(float) * 2 * o->cb_dim * T);
@@ -708,7 +718,7 @@ int voc_oracle_stage_shape(const VocOracle *o, int T, int stage, int *C, int64_t
     VOC_ST(c, l);
     for (int b = 0; b < o->n_blocks; b++) {
         c /= 2;
-        l = (l - 1) * o->rates[b];
+        l = o->trim_right_only ? l * o->rates[b] : (l - 1) * o->rates[b];
         for (int u = 0; u < 4; u++) VOC_ST(c, l);
     }
     VOC_ST(1, l);
@@ -719,6 +729,21 @@ int voc_oracle_stage_shape(const VocOracle *o, int T, int stage, int *C, int64_t
 #ifdef _OPENMP
 #include <omp.h>
 #endif
+/* Known-answer hook: the transposed conv alone under either trim policy (tests/golden/transconv_trim.npz holds the
+ * outputs of transformers' Qwen3OmniMoeCausalTransConvNet = both sides and MimiConvTranspose1d = right only).
+ * Returns the output length; y may be NULL to query it. */
+int64_t voc_oracle_transconv(const float *x, int Cin, int64_t L, const float *w, const float *b, int Cout, int K, int s,
+                             int right_only, float *y) {
+    int keep_b = g_bf16, keep_t = g_trim_right;
+    g_bf16 = 0;
+    g_trim_right = right_only != 0;
+    int64_t Lo = transconv_len(L, K, s);
+    if (y) transconv_causal(x, Cin, L, w, b, Cout, K, s, y);
+    g_bf16 = keep_b;
+    g_trim_right = keep_t;
+    return Lo;
+}
+
 /* Number of OpenMP threads the oracle uses from now on (returns what is in effect). */
 int voc_oracle_set_threads(int n) {
 #ifdef _OPENMP

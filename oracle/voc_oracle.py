@@ -49,6 +49,9 @@ def lib():
         L.voc_oracle_stage_shape.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
         L.voc_oracle_synthesize.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
                                             C.POINTER(C.c_size_t)]
+        L.voc_oracle_transconv.restype = C.c_int64
+        L.voc_oracle_transconv.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                           C.c_int, C.c_void_p]
         L.voc_oracle_pcm16.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
         L.voc_oracle_codes_from_le.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
         _lib = L
@@ -122,6 +125,20 @@ class Oracle:
         if rc:
             raise RuntimeError("oracle synthesize: " + self._err())
         return out[: n.value]
+
+
+def transconv(x: np.ndarray, w: np.ndarray, b: Optional[np.ndarray], stride: int, right_only: bool) -> np.ndarray:
+    """x [Cin, L], w [Cin, Cout, K] (ConvTranspose1d layout), b [Cout] -> y [Cout, Lout] under the given trim policy."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    bb = None if b is None else np.ascontiguousarray(b, dtype=np.float32)
+    cin, L = x.shape
+    _, cout, K = w.shape
+    bp = None if bb is None else bb.ctypes.data
+    Lo = int(lib().voc_oracle_transconv(x.ctypes.data, cin, L, w.ctypes.data, bp, cout, K, stride, int(right_only), None))
+    y = np.empty((cout, Lo), dtype=np.float32)
+    lib().voc_oracle_transconv(x.ctypes.data, cin, L, w.ctypes.data, bp, cout, K, stride, int(right_only), y.ctypes.data)
+    return y
 
 
 def set_threads(n: int) -> int:

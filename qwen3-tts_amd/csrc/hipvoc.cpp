@@ -104,6 +104,7 @@ struct Ctx {
     bool post_snake = true;
     bool phase_major = true;   // transposed-conv rows phase-major (HIPVOC_PHASE_MAJOR=0: channel-major)
     bool packed = true;        // bf16 mode: GEMM-to-GEMM tensors of the decoder stack exchanged as packed bf16 (HIPVOC_PACKED=0: fp32)
+    bool trim_right = false;   // trans-conv trim policy (metadata transconv_trim_right_only=1): keep L*r samples instead of (L-1)*r
     bool is_encoder = false;   // handle made by hipvoc_enc_load (encoder.inc.cpp): the vocoder entry points refuse it
     bool bf16 = false;         // HIPVOC_DTYPE_BF16: conv-GEMM operands in bf16, fp32 accumulate, everything else fp32
     int dual_out = 1;          // un-fused residual units, SnakeBeta in the producer's epilogue: 0 never, 1 conv7 -> conv1 only
@@ -166,10 +167,14 @@ struct Ctx {
         if (stream) (void)hipStreamDestroy(stream);
     }
 
+    // length after a decoder trans-conv (k = 2r, stride r): r samples trimmed on both sides (default; the sibling
+    // Qwen3OmniMoeCausalTransConvNet) or on the right only (Mimi's causal form): SURVEY.md 8a asks for the switch, since the
+    // shipped vocoder.onnx cannot be inspected offline
+    int64_t tc_len(int64_t L, int r) const { return trim_right ? L * r : (L - 1) * r; }
     int64_t out_len(int T) const {
         int64_t L = T;
         for (int r : up_ratio) L *= r;
-        for (int r : rates) L = (L - 1) * r;
+        for (int r : rates) L = tc_len(L, r);
         return L;
     }
 };
@@ -350,6 +355,8 @@ struct Loader {
         int Cin = (int)sh[0], Co = (int)sh[1], K = (int)sh[2];
         g.Cin = Cin; g.N = Co * s; g.TN = pick_tn(g.N); g.NP = rup(g.N, 32 * g.TN);
         g.ntaps = K / s; g.shift0 = 0; g.step = 1; g.S = s;
+        // right-only trim with K == 2s: y[q*s+r] = W[r+s] x[q-1] + W[r] x[q] -- the same two weight planes one input earlier
+        if (c->trim_right && K == 2 * s) g.shift0 = -1;
         // phase-major rows: a lane's four consecutive accumulator rows are four channels of one output position (bf16
         // mode: 8-byte stores into the packed tensors instead of four 2-byte ones; both modes: one integer division
         // per half tile in the epilogue instead of one per row)
@@ -382,6 +389,7 @@ static bool load_model(Ctx *c, const char *path, std::string &err) {
     if (md.count("sliding_window")) c->window = atoi(md["sliding_window"].c_str());
     if (md.count("rope_theta")) c->rope_theta = (float)atof(md["rope_theta"].c_str());
     if (md.count("rms_norm_eps")) c->rms_eps = (float)atof(md["rms_norm_eps"].c_str());
+    if (md.count("transconv_trim_right_only")) c->trim_right = atoi(md["transconv_trim_right_only"].c_str()) != 0;
     if (c->n_heads < 1 || c->window < 1) { err = "bad metadata"; return false; }
 
     const std::string D = "decoder.";
@@ -592,7 +600,7 @@ struct PlanBuilder {
         a.sn_a = sn ? sn->ea : nullptr; a.sn_ib = sn ? sn->ib : nullptr;
         a.Cin = g.Cin; a.N = g.N; a.NP = g.NP; a.TN = g.TN;
         a.ntaps = g.ntaps; a.shift0 = g.shift0; a.shift_step = g.step; a.S = g.S; a.pm = g.pm; a.act = act;
-        int M = g.S > 1 ? (g.ntaps == 2 ? Lin - 1 : Lin) : Lin;
+        int M = g.S > 1 ? (g.ntaps == 2 && !c->trim_right ? Lin - 1 : Lin) : Lin;
         bool flat = g.ntaps == 1 && (g.S == 1 ? Lpi == Lpo : Lpo == g.S * Lpi) && s2d <= 1;
         if (s2d > 1) M = Lin / s2d * s2d;      // (Lpo then is the padded length of the space-to-depth tensor)
         if (flat) {
@@ -709,7 +717,7 @@ static Plan *get_plan(Ctx *c, int G, int T, bool debug = false) {
         big = std::max(big, (size_t)c->dec_dim * rup((int)L, 4));
         C = c->dec_dim;
         for (size_t i = 0; i < c->blocks.size(); i++) {
-            L = (L - 1) * c->rates[i];
+            L = c->tc_len(L, c->rates[i]);
             C = c->blocks[i].tc.N / c->rates[i];
             big = std::max(big, (size_t)C * rup((int)L, 4));
             if (c->dual_out >= 2 && !blk_fused(c->blocks[i])) snk_floats = std::max(snk_floats, (size_t)C * rup((int)L, 4) * G);
@@ -773,7 +781,7 @@ static Plan *get_plan(Ctx *c, int G, int T, bool debug = false) {
         for (size_t bi = 0; bi < c->blocks.size(); bi++) {
             const Ctx::Block &blk = c->blocks[bi];
             const int r = c->rates[bi];
-            const int L2 = (L - 1) * r, Lp2 = rup(L2, 4);
+            const int L2 = (int)c->tc_len(L, r), Lp2 = rup(L2, 4);
             const size_t ni = std::min<size_t>(bi, 4);
             const bool fused_blk = blk_fused(blk);
             // trans-conv: packed in; fp32 x0 (the residual stream) and packed snake_s1(x0) out
@@ -821,7 +829,7 @@ static Plan *get_plan(Ctx *c, int G, int T, bool debug = false) {
         for (size_t bi = 0; bi < c->blocks.size(); bi++) {
             const Ctx::Block &blk = c->blocks[bi];
             int r = c->rates[bi];
-            int L2 = (L - 1) * r, Lp2 = rup(L2, 4);
+            int L2 = (int)c->tc_len(L, r), Lp2 = rup(L2, 4);
             size_t ni = std::min<size_t>(bi, 4);
             // Un-fused residual units (blocks whose channels do not fit one row tile): every SnakeBeta of the chain is
             // evaluated by the PRODUCER of the tensor it acts on, once per element, instead of in the consumer's

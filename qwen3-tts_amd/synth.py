@@ -37,13 +37,16 @@ class DecoderConfig:
     upsampling_ratios: Tuple[int, ...] = (2, 2)
     upsample_rates: Tuple[int, ...] = (8, 5, 4, 3)
     decoder_dim: int = 1536
+    # trans-conv trim policy (unverifiable offline, hence a switch): False = k - s samples off both sides
+    # ((L-1)*r, 1920*T - 555 per unit), True = off the right only (L*r, exactly 1920*T per unit)
+    transconv_trim_right_only: bool = False
 
     def out_len(self, frames: int) -> int:
         n = frames
         for r in self.upsampling_ratios:
             n *= r
         for r in self.upsample_rates:
-            n = (n - 1) * r
+            n = n * r if self.transconv_trim_right_only else (n - 1) * r
         return n
 
     def metadata(self) -> Dict[str, str]:
@@ -52,6 +55,7 @@ class DecoderConfig:
             "sliding_window": str(self.sliding_window),
             "rope_theta": repr(float(self.rope_theta)),
             "rms_norm_eps": repr(float(self.rms_norm_eps)),
+            "transconv_trim_right_only": "1" if self.transconv_trim_right_only else "0",
         }
 
 
@@ -59,6 +63,10 @@ FULL = DecoderConfig()
 # Same topology (so 1 frame is still 1920 samples, protocol.rs:122), narrow channels: CPU-test size.
 SMALL = DecoderConfig(codebook_size=64, codebook_dim=64, latent_dim=64, hidden_size=64, num_hidden_layers=2,
                       num_attention_heads=2, head_dim=32, intermediate_size=96, decoder_dim=512)
+# the other trans-conv trim policy (exactly 1920 samples per frame)
+SMALL_TRIM_RIGHT = DecoderConfig(codebook_size=64, codebook_dim=64, latent_dim=64, hidden_size=64, num_hidden_layers=2,
+                                 num_attention_heads=2, head_dim=32, intermediate_size=96, decoder_dim=512,
+                                 transconv_trim_right_only=True)
 # Odd widths: channel counts that are not multiples of the kernel tiles (exercises the masks).
 ODD = DecoderConfig(codebook_size=50, codebook_dim=40, latent_dim=72, hidden_size=48, num_hidden_layers=1,
                     num_attention_heads=3, head_dim=16, intermediate_size=80, decoder_dim=208,

@@ -273,3 +273,34 @@ def test_full_size_properties_batch_and_sharded_stream(pkg, synth):
     utts = [synth.make_codes(125, 1000 + u, cfg) for u in range(5)]
     for got, c in zip(v.synthesize_batch(utts), utts):
         assert np.array_equal(got, v.synthesize(c))
+
+
+def test_right_only_transconv_trim_policy(pkg, synth, vo):
+    """The other trans-conv trim policy (metadata transconv_trim_right_only=1; SURVEY.md 8a: which one the shipped
+    vocoder.onnx has is unverifiable offline): every stage and the chunk loop against the oracle, exactly 1920 samples
+    per frame, in fp32 and in the bf16 mode (packed exchange)."""
+    cfg = synth.SMALL_TRIM_RIGHT
+    W = synth.make_weights(cfg, 0)
+    path = os.path.join(tempfile.gettempdir(), "hipvoc_test_SMALL_TRIM_RIGHT.safetensors")
+    synth.save_safetensors(path, W, cfg.metadata())
+    md = {k: float(v) for k, v in cfg.metadata().items()}
+    o = vo.Oracle(W, md)
+    v = pkg.HipVocoder.load(path, device=0, unit_frames=4)
+    assert v.unit_samples == 4 * 1920
+    codes = synth.make_codes(4, 77, cfg)
+    for s in range(1, v.n_stages):
+        ref = o.stage(codes, s)
+        got = v.stage(codes, s, ref.size + 8)
+        assert got.shape == ref.shape, s
+        assert np.abs(got - ref).max() <= 1e-3 * max(1.0, float(np.abs(ref).max())), s
+    for n in (1, 4, 7, 10):
+        c = synth.make_codes(n, 90 + n, cfg)
+        got, ref = v.synthesize(c), o.synthesize(c, 4)
+        assert got.size == ref.size == n * 1920
+        assert np.abs(got - ref).max() <= 1e-3 and snr_db(ref, got) >= 60.0
+    vb = pkg.HipVocoder.load(path, device=0, unit_frames=4, dtype=1)
+    ob = vo.Oracle(W, {**md, "bf16_gemm": 1.0})
+    c = synth.make_codes(10, 5, cfg)
+    gb = vb.synthesize(c)
+    assert gb.size == 10 * 1920
+    assert snr_db(o.synthesize(c, 4), gb) >= 30.0 and snr_db(ob.synthesize(c, 4), gb) >= 30.0

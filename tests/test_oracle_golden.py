@@ -103,3 +103,30 @@ def test_out_of_range_code_is_an_error(vo, synth):
     codes[1, 3] = synth.SMALL.codebook_size
     with pytest.raises(RuntimeError):
         o.run_unit(codes)
+
+
+def test_transconv_trim_policies_match_transformers(vo):
+    """Both trim policies of the decoder's transposed convs (SURVEY.md 8a asks for the switch: which one the shipped
+    vocoder.onnx has cannot be verified offline) against transformers: Qwen3OmniMoeCausalTransConvNet (both sides, the
+    default) and Mimi's causal MimiConvTranspose1d (right only).  Fixture: tools/gen_transconv_trim_golden.py."""
+    g = load_golden("transconv_trim")
+    for name in ("a", "b", "c"):
+        x, w, b, s = g[f"{name}_x"], g[f"{name}_w"], g[f"{name}_b"], int(g[f"{name}_stride"])
+        for policy, right in (("both", False), ("right", True)):
+            y = vo.transconv(x, w, b, s, right)
+            ref = g[f"{name}_{policy}"]
+            assert y.shape == ref.shape, (name, policy, y.shape, ref.shape)
+            assert ref.size == 0 or np.abs(y - ref).max() <= 1e-5, (name, policy)      # (one input, both sides: empty)
+        L = x.shape[1]
+        assert g[f"{name}_both"].shape[1] == (L - 1) * s and g[f"{name}_right"].shape[1] == L * s
+
+
+def test_right_only_trim_gives_exactly_1920_samples_per_frame(vo, synth):
+    cfg = synth.SMALL_TRIM_RIGHT
+    o = vo.Oracle(synth.make_weights(cfg, 0), {k: float(v) for k, v in cfg.metadata().items()})
+    for T in (1, 3, 4):
+        assert o.out_len(T) == cfg.out_len(T) == 1920 * T
+        assert o.run_unit(synth.make_codes(T, T, cfg)).size == 1920 * T
+    # the chunk loop then keeps every sample of every unit (vocoder.rs:79-80: the .min() is a no-op)
+    codes = synth.make_codes(10, 5, cfg)
+    assert o.synthesize(codes, 4).size == 10 * 1920
