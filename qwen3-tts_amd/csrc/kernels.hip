@@ -923,44 +923,50 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const float *x, float *
                                                           const float *bias, const float *sn_a, const float *sn_ib,
                                                           int C, int G, int L, int Lp, long out_stride,
                                                           int vec_store) {
-    int t = (blockIdx.x * 256 + threadIdx.x) * 4;
+    // 4 consecutive samples per thread: they need the activations of positions t-6 .. t+3, i.e. 5 aligned pairs for
+    // the packed SnakeBeta.  (8 samples per thread -- 7 pairs for 8 outputs -- was measured 45 % SLOWER: the kernel is
+    // bound by its access pattern, and a 32-byte lane stride halves the use of every load instruction.)
+    constexpr int NO = 4;
+    static_assert(K <= 7, "halo of 8 positions");
+    int t = (blockIdx.x * 256 + threadIdx.x) * NO;
     int u = blockIdx.y;
     if (t >= L) return;
     long cs = (long)G * Lp;
     const float *xu = x + (long)u * Lp;
-    float acc[4];
+    float acc[NO];
     float b0 = bias ? bias[0] : 0.0f;
 #pragma unroll
-    for (int i = 0; i < 4; i++) acc[i] = b0;
+    for (int i = 0; i < NO; i++) acc[i] = b0;
     for (int c = 0; c < C; c++) {
         const float *xr = xu + (long)c * cs;
         float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
         float4 v0 = t >= 8 ? *reinterpret_cast<const float4 *>(xr + t - 8) : z;
         float4 v1 = t >= 4 ? *reinterpret_cast<const float4 *>(xr + t - 4) : z;
         float4 v2 = *reinterpret_cast<const float4 *>(xr + t);
-        float sa = sn_a[c], sib = sn_ib[c];
+        const f32x2 sa = (f32x2)(sn_a[c]), sib = (f32x2)(sn_ib[c]);
         float sv[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
 #pragma unroll
-        for (int i = 0; i < 12; i++) {
+        for (int i = 2; i < 12; i += 2) {             // (sv[0], sv[1] are never read: K - 1 <= 6)
+            f32x2 s2 = snake_beta2(mk2(sv[i], sv[i + 1]), sa, sib);
             int pos = t - 8 + i;
-            float s = snake_beta(sv[i], sa, sib);
-            sv[i] = (pos >= 0 && pos < L) ? s : 0.0f;       // zero padding applies to the activation output
+            sv[i] = (pos >= 0 && pos < L) ? s2.x : 0.0f;            // zero padding applies to the activation output
+            sv[i + 1] = (pos + 1 >= 0 && pos + 1 < L) ? s2.y : 0.0f;
         }
 #pragma unroll
         for (int j = 0; j < K; j++) {
             float wv = w[c * K + j];
 #pragma unroll
-            for (int i = 0; i < 4; i++) acc[i] += wv * sv[8 + i - (K - 1) + j];   // sample t+i reads activation t+i-(K-1-j)
+            for (int i = 0; i < NO; i++) acc[i] += wv * sv[8 + i - (K - 1) + j];   // sample t+i reads activation t+i-(K-1-j)
         }
     }
     float *o = out + (long)u * out_stride + t;
 #pragma unroll
-    for (int i = 0; i < 4; i++) acc[i] = fminf(fmaxf(acc[i], -1.0f), 1.0f);
-    if (vec_store && t + 4 <= L) {
+    for (int i = 0; i < NO; i++) acc[i] = fminf(fmaxf(acc[i], -1.0f), 1.0f);
+    if (vec_store && t + NO <= L) {
         *reinterpret_cast<float4 *>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
     } else {
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+        for (int i = 0; i < NO; i++)
             if (t + i < L) o[i] = acc[i];
     }
 }
