@@ -63,6 +63,9 @@ FULL = DecoderConfig()
 # Same topology (so 1 frame is still 1920 samples, protocol.rs:122), narrow channels: CPU-test size.
 SMALL = DecoderConfig(codebook_size=64, codebook_dim=64, latent_dim=64, hidden_size=64, num_hidden_layers=2,
                       num_attention_heads=2, head_dim=32, intermediate_size=96, decoder_dim=512)
+# every channel count a multiple of 8 (so the bf16 packed exchange is on) but not of the 32-row tiles: 320, 160, 80, 40
+PAD8 = DecoderConfig(codebook_size=32, codebook_dim=32, latent_dim=40, hidden_size=32, num_hidden_layers=1,
+                     num_attention_heads=2, head_dim=16, intermediate_size=48, decoder_dim=640)
 # the other trans-conv trim policy (exactly 1920 samples per frame)
 SMALL_TRIM_RIGHT = DecoderConfig(codebook_size=64, codebook_dim=64, latent_dim=64, hidden_size=64, num_hidden_layers=2,
                                  num_attention_heads=2, head_dim=32, intermediate_size=96, decoder_dim=512,

@@ -132,7 +132,7 @@ def test_bf16_deterministic(pkg, synth):
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
-@pytest.mark.parametrize("cfg_name,unit,frames", [("SMALL", 4, 10), ("FULL", 8, 8)])
+@pytest.mark.parametrize("cfg_name,unit,frames", [("SMALL", 4, 10), ("FULL", 8, 8), ("PAD8", 3, 7)])
 def test_bf16_packed_dataflow_equals_fp32_exchange_bitwise(pkg, synth, cfg_name, unit, frames):
     """Production bf16 plans exchange GEMM-to-GEMM tensors of the decoder stack as packed bf16 with the consumer's
     SnakeBeta applied by the producer (ConvGemmArgs::xb / yb); HIPVOC_PACKED=0 keeps them fp32 and rounds in the
@@ -157,3 +157,27 @@ def test_bf16_packed_dataflow_equals_fp32_exchange_bitwise(pkg, synth, cfg_name,
     b = packed.synthesize(codes)
     assert a.size == b.size and a.size > 0
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), float(np.abs(a - b).max())
+
+
+def test_channel_counts_that_pad_the_row_tiles(pkg, synth, vo):
+    """PAD8: 320 / 160 / 80 / 40 decoder channels -- multiples of 8 (packed exchange on) whose 32-row tiles are partly
+    padding, with fused (80, 40) and un-fused (320, 160) residual units: fp32 within the fp32 gates, bf16 within its
+    stated tolerance, stage by stage against the emulation."""
+    cfg = synth.PAD8
+    W = weights_for(synth, "PAD8", 0)
+    path = os.path.join(tempfile.gettempdir(), "hipvoc_test_PAD8_0.safetensors")
+    synth.save_safetensors(path, W, cfg.metadata())
+    md = {k: float(v) for k, v in cfg.metadata().items()}
+    o32, ob = vo.Oracle(W, md), vo.Oracle(W, {**md, "bf16_gemm": 1.0})
+    codes = synth.make_codes(7, 3, cfg)
+    v32 = pkg.HipVocoder.load(path, device=0, unit_frames=3)
+    got, ref = v32.synthesize(codes), o32.synthesize(codes, 3)
+    assert got.size == ref.size and np.abs(got - ref).max() <= 1e-3 and snr_db(ref, got) >= 60.0
+    vb = pkg.HipVocoder.load(path, device=0, unit_frames=3, dtype=BF16)
+    c3 = codes[:3]
+    for s in range(1, vb.n_stages):
+        rb = ob.stage(c3, s)
+        g = vb.stage(c3, s, rb.size + 8)
+        assert g.shape == rb.shape and snr_db(rb, g) >= 30.0, (s, snr_db(rb, g))
+    gb = vb.synthesize(codes)
+    assert snr_db(ref, gb) >= WAV_SNR_DB and np.abs(gb - ref).max() <= WAV_MAX_ABS
