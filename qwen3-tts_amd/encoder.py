@@ -64,6 +64,51 @@ def resample(samples, from_rate: int, to_rate: int) -> np.ndarray:
     return out
 
 
+def read_wav(path: str):
+    """Minimal RIFF/WAVE reader for what hound hands the reference (speech_tokenizer.rs:681-696): PCM integer of 8 / 16 /
+    24 / 32 bits (scaled by 1 / 2^(bits-1); 8-bit files are unsigned, offset 128, as hound reads them) and IEEE float32.
+    -> (interleaved float32 samples, sample_rate, channels).  Raises ValueError on anything else."""
+    import struct
+    with open(path, "rb") as f:
+        data = f.read()
+    if len(data) < 12 or data[:4] != b"RIFF" or data[8:12] != b"WAVE":
+        raise ValueError(f"Failed to open WAV file: {path}")
+    pos, fmt, payload = 12, None, None
+    while pos + 8 <= len(data):
+        cid, size = data[pos:pos + 4], struct.unpack("<I", data[pos + 4:pos + 8])[0]
+        body = data[pos + 8: pos + 8 + size]
+        if cid == b"fmt ":
+            fmt = body
+        elif cid == b"data":
+            payload = body
+        pos += 8 + size + (size & 1)
+    if fmt is None or payload is None or len(fmt) < 16:
+        raise ValueError(f"Failed to open WAV file: {path} (missing fmt / data chunk)")
+    tag, channels, rate, _, _, bits = struct.unpack("<HHIIHH", fmt[:16])
+    if tag == 0xFFFE and len(fmt) >= 26:                      # WAVE_FORMAT_EXTENSIBLE: the real tag leads the sub-format GUID
+        tag = struct.unpack("<H", fmt[24:26])[0]
+    if channels < 1 or rate < 1:
+        raise ValueError("WAV: bad channel count / sample rate")
+    if tag == 3 and bits == 32:
+        x = np.frombuffer(payload[: len(payload) // 4 * 4], dtype="<f4").astype(np.float32)
+    elif tag == 1 and bits in (8, 16, 24, 32):
+        scale = np.float32(1 << (bits - 1))
+        if bits == 8:
+            v = np.frombuffer(payload, dtype=np.uint8).astype(np.int32) - 128
+        elif bits == 16:
+            v = np.frombuffer(payload[: len(payload) // 2 * 2], dtype="<i2").astype(np.int32)
+        elif bits == 32:
+            v = np.frombuffer(payload[: len(payload) // 4 * 4], dtype="<i4")
+        else:
+            b = np.frombuffer(payload[: len(payload) // 3 * 3], dtype=np.uint8).reshape(-1, 3).astype(np.int32)
+            v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
+            v = np.where(v >= 1 << 23, v - (1 << 24), v)
+        x = (v.astype(np.float32) / scale).astype(np.float32)      # `s as f32 / max_val`
+    else:
+        raise ValueError(f"WAV: unsupported sample format (tag {tag}, {bits} bits)")
+    return x, int(rate), int(channels)
+
+
 class HipSpeechTokenizer:
     """SpeechTokenizer: 24 kHz mono waveform -> codec tokens on one MI355X (speech_tokenizer.rs:608-675)."""
 
@@ -141,6 +186,13 @@ class HipSpeechTokenizer:
         if sample_rate != SAMPLE_RATE:
             x = resample(x, sample_rate, SAMPLE_RATE)
         return self.encode(x)
+
+    def encode_wav(self, wav_path: str) -> np.ndarray:
+        """SpeechTokenizer::encode_wav (speech_tokenizer.rs:680-721): RIFF/WAVE file -> codes.  Integer samples are
+        divided by 2^(bits-1) (687-691), float samples taken as they are (693-695); then mono mix and resampling as in
+        encode_samples."""
+        samples, rate, channels = read_wav(wav_path)
+        return self.encode_samples(samples, rate, channels)
 
     # ---- parity hooks ----------------------------------------------------------------------
     @property

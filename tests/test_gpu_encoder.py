@@ -284,3 +284,27 @@ def test_full_size_batch_properties(pkg, synth):
     # codes are not degenerate: many distinct entries of every codebook are used across the batch
     for q in (0, 1, 15):
         assert np.unique(first[:4, :, q]).size > 50
+
+
+def test_encode_wav_end_to_end_writes_a_voice_profile(pkg, synth, eo, tmp_path):
+    """encode_wav (speech_tokenizer.rs:680-721) and what its two callers do with the result (main.rs:440-472,
+    api/openai.rs:322-345): a 16 kHz stereo 16-bit WAV -> codes -> voice JSON -> read back by the voice loader."""
+    import wave
+    e = enc_for(pkg, synth, "ENC_SMALL")
+    rng = np.random.default_rng(3)
+    left = (0.25 * synth.make_audio(16000 * 2, 5)).astype(np.float32)
+    right = (0.5 * left + 0.01 * rng.standard_normal(left.size)).astype(np.float32)
+    pcm = np.stack([left, right], axis=1)
+    i16 = np.clip(np.round(pcm * 32767), -32768, 32767).astype(np.int16)
+    p = str(tmp_path / "speaker.wav")
+    with wave.open(p, "wb") as w:
+        w.setnchannels(2); w.setsampwidth(2); w.setframerate(16000); w.writeframes(i16.tobytes())
+    codes = e.encode_wav(p)
+    f = i16.astype(np.float32) / np.float32(32768)
+    mono = ((f[:, 0] + f[:, 1]) / np.float32(2)).astype(np.float32)
+    want = e.encode(eo.resample(mono, 16000, 24000))
+    assert codes.shape == want.shape == (25, 16) and np.array_equal(codes, want)        # 2 s -> 48000 samples -> 25 frames
+    out = str(tmp_path / "speaker.json")
+    pkg.voice.save_voice_json(out, codes, "two seconds of a synthetic voice")
+    back, text = pkg.voice.load_voice_file(out)
+    assert np.array_equal(back, codes) and text.startswith("two seconds")
