@@ -117,10 +117,11 @@ hipError_t launch_layernorm(const float *x, float *y, const float *w, const floa
 #endif
 static constexpr int FB = HIPVOC_RVQ_FB;    // frames per workgroup
 static constexpr int CPT = 4;   // consecutive codewords per thread
+static constexpr int PF = 4;    // k-steps of codeword prefetch (register ring)
 static constexpr int NT = 512;  // threads: 2048 codewords / CPT.  (256 threads x 8 codewords left 1000 equal, long-running
                                 // workgroups for 768 slots: a second round at 30 % fill; 512 threads give ~2 even rounds)
 
-__global__ __launch_bounds__(NT) void rvq_encode_kernel(RvqEncArgs a) {
+__global__ __launch_bounds__(NT, 4) void rvq_encode_kernel(RvqEncArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *hs = smem;                  // [dim][FB]
     float *xs = hs + a.dim * FB;       // [D][FB] residual
@@ -194,16 +195,7 @@ __global__ __launch_bounds__(NT) void rvq_encode_kernel(RvqEncArgs a) {
                 for (int j = 0; j < CPT; j++)
 #pragma unroll
                     for (int f = 0; f < FB; f++) acc[j][f] = 0.0f;
-                for (int d = 0; d < a.D; d++) {
-                    float e[CPT];
-                    const float *ep = et + (long)d * a.cb_size + c0;
-                    if (vec) {
-                        const float4 e0 = *reinterpret_cast<const float4 *>(ep);
-                        e[0] = e0.x; e[1] = e0.y; e[2] = e0.z; e[3] = e0.w;
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < CPT; j++) e[j] = c0 + j < a.cb_size ? ep[j] : 0.0f;
-                    }
+                auto step = [&](int d, const float *e) {
                     float xv[FB];
 #pragma unroll
                     for (int f4 = 0; f4 < FB / 4; f4++) {
@@ -214,6 +206,33 @@ __global__ __launch_bounds__(NT) void rvq_encode_kernel(RvqEncArgs a) {
                     for (int j = 0; j < CPT; j++)
 #pragma unroll
                         for (int f = 0; f < FB; f++) acc[j][f] = __builtin_fmaf(xv[f], e[j], acc[j][f]);
+                };
+                if (vec && (a.D % PF) == 0) {
+                    // codeword values travel PF k-steps ahead of their use in a register ring: one k-step's 32 FMAs are
+                    // ~50 ns, an L2 hit ~600 ns, and four waves per SIMD alone do not cover the difference
+                    static_assert(CPT == 4, "one float4 per k-step");
+                    float4 ring[PF];
+                    const float *ep = et + c0;
+#pragma unroll
+                    for (int i = 0; i < PF; i++) ring[i] = *reinterpret_cast<const float4 *>(ep + (long)i * a.cb_size);
+                    for (int d0 = 0; d0 < a.D; d0 += PF) {
+#pragma unroll
+                        for (int i = 0; i < PF; i++) {
+                            const float4 cur = ring[i];
+                            const int dn = d0 + i + PF;
+                            if (dn < a.D) ring[i] = *reinterpret_cast<const float4 *>(ep + (long)dn * a.cb_size);
+                            const float e[CPT] = {cur.x, cur.y, cur.z, cur.w};
+                            step(d0 + i, e);
+                        }
+                    }
+                } else {
+                    for (int d = 0; d < a.D; d++) {
+                        float e[CPT];
+                        const float *ep = et + (long)d * a.cb_size + c0;
+#pragma unroll
+                        for (int j = 0; j < CPT; j++) e[j] = c0 + j < a.cb_size ? ep[j] : 0.0f;
+                        step(d, e);
+                    }
                 }
 #pragma unroll
                 for (int j = 0; j < CPT; j++) {
