@@ -45,7 +45,7 @@ static constexpr int BK = 16;    // input channels per K stage
 
 // ENC: the encoder path's variant (ELU on the input, ELU / tanh-GELU epilogues); compiled out of the vocoder's kernels
 template <int TN, bool FUSE, int NW, bool ENC = false>
-__global__ __launch_bounds__(NW * 64, (FUSE && TN > 4) ? 2 : 4) void conv_gemm_kernel(ConvGemmArgs a, int HL, int XW, int tiles_per_unit,
+__global__ __launch_bounds__(NW * 64, (FUSE && TN > 4) ? 3 : 4) void conv_gemm_kernel(ConvGemmArgs a, int HL, int XW, int tiles_per_unit,
                                                                            int n_tiles) {
     constexpr int NTH = NW * 64;                     // NW waves; the workgroup covers BM = 32*NW positions
     constexpr int BM = NW * 32;
