@@ -142,3 +142,26 @@ def test_wire_codec_survives_fuzzing_under_asan_ubsan(tmp_path):
     assert r.returncode == 0, r.stderr
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "fuzz_wire OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_shared_known_answers_fixture(wire):
+    """tests/golden/wire_kat.json: the same bytes integration/wire_kat_test.rs asserts against rmp-serde on a box with
+    cargo.  Here: the C codec produces / parses them, and the independent msgpack package agrees."""
+    import json
+    import os
+    kat = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "wire_kat.json")))
+    b = {k: bytes.fromhex(v) for k, v in kat.items() if not k.startswith("_")}
+    assert wire.request_ping() == b["request_ping"]
+    assert wire.request_init("vocoder", "/models") == b["request_init_vocoder_models"]
+    assert wire.parse_request(b["request_ping"])[0] == wire.PING
+    assert wire.parse_request(b["request_init_vocoder_models"])[0] == wire.INIT
+    assert wire.parse_request(b["request_vocode_codes_01_80_ff_n0"]) == (wire.VOCODE, bytes([1, 0x80, 0xFF]), 0)
+    assert wire.encode_simple_response(True, "Ping") == b["response_ok_ping"]
+    assert wire.encode_simple_response(False, "Init", "x") == b["response_error_init_x"]
+    assert wire.encode_vocode_response(np.array([-32768], dtype=np.int16)) == b["response_ok_vocode_audio_00_80_n1"]
+    assert msgpack.packb("Ping") == b["request_ping"]
+    assert msgpack.packb({"Init": ["vocoder", "/models"]}) == b["request_init_vocoder_models"]
+    assert msgpack.packb({"Vocode": [[1, 0x80, 0xFF], 0]}) == b["request_vocode_codes_01_80_ff_n0"]
+    assert msgpack.packb(["ok", "Ping", None]) == b["response_ok_ping"]
+    assert msgpack.packb(["error", "Init", "x"]) == b["response_error_init_x"]
+    assert msgpack.packb(["ok", {"Vocode": [[0, 0x80], 1]}, None]) == b["response_ok_vocode_audio_00_80_n1"]
