@@ -177,8 +177,8 @@ def main():
         Lw = voc.unit_samples
         alg = {
             "final_conv_kernel<7>": G * (cfg.decoder_dim // 16 * Lw + Lw) * 4,   # C=96 activations in, 1 channel out
-            "dwconv_ln_kernel": dw_bytes,
-            "rmsnorm_kernel": (2 * cfg.num_hidden_layers + 1) * 2 * cfg.hidden_size * G * T * 4,
+            next((k for k in kernels if k.startswith("dwconv_ln")), "dwconv_ln_kernel"): dw_bytes,
+            next((k for k in kernels if k.startswith("rmsnorm")), "rmsnorm_kernel"): (2 * cfg.num_hidden_layers + 1) * 2 * cfg.hidden_size * G * T * 4,
             "swiglu_kernel": cfg.num_hidden_layers * 3 * cfg.intermediate_size * G * T * 4,
         }
         for k, b in alg.items():

@@ -353,13 +353,13 @@ static Plan *enc_get_plan(Ctx *c, EncModel *m, int G, long n, bool debug) {
         const float eps = m->ln_eps;
         for (const EncModel::Layer &ly : m->layers) {
             float *hh = h;
-            b.add("enc_layernorm", "layernorm_kernel", 0, [=](hipStream_t s) { return launch_layernorm(hh, xn, ly.ln1w, ly.ln1b, D, P, eps, s); });
+            b.add("enc_layernorm", layernorm_kernel_name(D), 0, [=](hipStream_t s) { return launch_layernorm(hh, xn, ly.ln1w, ly.ln1b, D, P, eps, s); });
             b.gemm("enc_qkv", ly.qkv, xn, T, Tp, qkv, Tp, nullptr, nullptr, nullptr, ACT_NONE);
             b.add("enc_attention", attention_kernel_name(hd, T, win), (double)G * nh * T * std::min(T, win) * hd, [=](hipStream_t s) {
                 return launch_attention(qkv, ao, ct, sn, nh, hd, G, T, Tp, win, s);
             });
             b.gemm("enc_o_proj", ly.o, ao, T, Tp, h, Tp, nullptr, h, ly.ls1, ACT_NONE);
-            b.add("enc_layernorm", "layernorm_kernel", 0, [=](hipStream_t s) { return launch_layernorm(hh, xn, ly.ln2w, ly.ln2b, D, P, eps, s); });
+            b.add("enc_layernorm", layernorm_kernel_name(D), 0, [=](hipStream_t s) { return launch_layernorm(hh, xn, ly.ln2w, ly.ln2b, D, P, eps, s); });
             b.gemm("enc_fc1", ly.fc1, xn, T, Tp, ffb, Tp, nullptr, nullptr, nullptr, ACT_GELU_TANH);
             if (!debug && &ly == &m->layers.back()) {      // the last layer's output only feeds the stride-2 conv
                 b.gemm("enc_fc2", ly.fc2, ffb, T, Tp, SD, dsTp, nullptr, h, ly.ls2, ACT_NONE, nullptr, nullptr, nullptr, nullptr, 0, dsr);

@@ -678,7 +678,7 @@ static Plan *get_plan(Ctx *c, int G, int T, bool debug = false) {
             const Ctx::Layer &ly = c->layers[li];
             int H = c->hidden;
             float eps = c->rms_eps;
-            b.add("rmsnorm", "rmsnorm_kernel", 0, [=](hipStream_t s) { return launch_rmsnorm(h, xn, ly.ln1, H, P, eps, s); });
+            b.add("rmsnorm", rmsnorm_kernel_name(H), 0, [=](hipStream_t s) { return launch_rmsnorm(h, xn, ly.ln1, H, P, eps, s); });
             b.gemm("qkv", ly.qkv, xn, T, Tp, qkv, Tp, nullptr, nullptr, nullptr, ACT_NONE);
             int nh = c->n_heads, hd = c->head_dim, win = c->window;
             const float *ct = c->cos_t, *sn = c->sin_t;
@@ -686,7 +686,7 @@ static Plan *get_plan(Ctx *c, int G, int T, bool debug = false) {
                 return launch_attention(qkv, ao, ct, sn, nh, hd, G, T, Tp, win, s);
             });
             b.gemm("o_proj", ly.o, ao, T, Tp, h, Tp, nullptr, h, ly.ls1, ACT_NONE);
-            b.add("rmsnorm", "rmsnorm_kernel", 0, [=](hipStream_t s) { return launch_rmsnorm(h, xn, ly.ln2, H, P, eps, s); });
+            b.add("rmsnorm", rmsnorm_kernel_name(H), 0, [=](hipStream_t s) { return launch_rmsnorm(h, xn, ly.ln2, H, P, eps, s); });
             b.gemm("gate_up", ly.gu, xn, T, Tp, gu, Tp, nullptr, nullptr, nullptr, ACT_NONE);
             long nI = (long)c->inter * P;
             b.add("swiglu", "swiglu_kernel", 0, [=](hipStream_t s) { return launch_swiglu(gu, gu + nI, nI, s); });
@@ -696,7 +696,7 @@ static Plan *get_plan(Ctx *c, int G, int T, bool debug = false) {
         const float *fw = c->final_norm;
         int H = c->hidden;
         float eps = c->rms_eps;
-        b.add("rmsnorm", "rmsnorm_kernel", 0, [=](hipStream_t s) { return launch_rmsnorm(h, xn, fw, H, P, eps, s); });
+        b.add("rmsnorm", rmsnorm_kernel_name(H), 0, [=](hipStream_t s) { return launch_rmsnorm(h, xn, fw, H, P, eps, s); });
     } else {
         xn = h;
     }
@@ -744,7 +744,7 @@ static Plan *get_plan(Ctx *c, int G, int T, bool debug = false) {
             float *y = t1;
             int CC = C, K = u.K, GG = G, LL = L, LLp = Lp;
             Ctx::Up uu = u;
-            b.add("dwconv_ln", "dwconv_ln_kernel", (double)G * L * C * K, [=](hipStream_t s) {
+            b.add("dwconv_ln", dwconv_ln_kernel_name(C, K), (double)G * L * C * K, [=](hipStream_t s) {
                 return launch_dwconv_ln(x, y, uu.dw_w, uu.dw_b, uu.ln_w, uu.ln_b, CC, K, GG, LL, LLp, 1e-6f, s);
             });
         }

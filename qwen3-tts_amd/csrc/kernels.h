@@ -65,6 +65,14 @@ struct ConvGemmArgs {
 };
 hipError_t launch_conv_gemm(const ConvGemmArgs &a, hipStream_t s);
 hipError_t launch_conv_gemm_bf16(const ConvGemmArgs &a, hipStream_t s);
+// kernels_gemm1.hip: the small-launch form of the fp32 1-tap GEMMs (bit-identical results); launch_conv_gemm
+// dispatches to it when gemm1_selected()
+bool gemm1_selected(const ConvGemmArgs &a);
+hipError_t launch_gemm1(const ConvGemmArgs &a, hipStream_t s);
+const char *gemm1_kernel_name(const ConvGemmArgs &a);
+bool gemm1_bf16_selected(const ConvGemmArgs &a);      // the same for the bf16 mode (launch_conv_gemm_bf16 dispatches)
+hipError_t launch_gemm1_bf16(const ConvGemmArgs &a, hipStream_t s);
+const char *gemm1_bf16_kernel_name(const ConvGemmArgs &a);
 const char *conv_gemm_bf16_kernel_name(const ConvGemmArgs &a);
 size_t conv_gemm_bf16_lds_bytes(const ConvGemmArgs &a);
 namespace detail {
@@ -89,6 +97,7 @@ hipError_t launch_rvq(const RvqArgs &a, hipStream_t s);
 
 // RMSNorm over channels of x[C][P] (P flat positions, channel stride P): y = w * (x * rsqrt(mean x^2 + eps))
 hipError_t launch_rmsnorm(const float *x, float *y, const float *w, int C, long P, float eps, hipStream_t s);
+const char *rmsnorm_kernel_name(int C);            // the symbol launch_rmsnorm picks, as rocprof prints it
 
 // Causal sliding-window attention with RoPE.  qkv[3*nh*hd][G][Lp] (rows: q | k | v), out[nh*hd][G][Lp].
 hipError_t launch_attention(const float *qkv, float *out, const float *cos_t, const float *sin_t, int nh, int hd,
@@ -102,6 +111,7 @@ hipError_t launch_swiglu(float *g, const float *u, long n, hipStream_t s);
 // ConvNeXt front half: depthwise causal conv k=K then LayerNorm over channels (eps) with affine.
 hipError_t launch_dwconv_ln(const float *x, float *y, const float *dw_w, const float *dw_b, const float *ln_w,
                             const float *ln_b, int C, int K, int G, int L, int Lp, float eps, hipStream_t s);
+const char *dwconv_ln_kernel_name(int C, int K);
 
 // Final stage: SnakeBeta -> causal conv C->1 (w[C][K], K == 7; other K: use conv_gemm) -> clamp; out[u*out_stride + t]
 hipError_t launch_final_conv(const float *x, float *out, const float *w, const float *bias, const float *sn_a,
@@ -118,6 +128,7 @@ hipError_t launch_s2d(const float *x, float *y, int C, int G, int L, int Lp, int
 hipError_t launch_tap_stack(const float *x, float *y, int K, int G, int L, int Lp, hipStream_t s);
 // LayerNorm with bias over channels of x[C][P] (speech_tokenizer.rs:394-403): biased variance, eps inside the sqrt
 hipError_t launch_layernorm(const float *x, float *y, const float *w, const float *b, int C, long P, float eps, hipStream_t s);
+const char *layernorm_kernel_name(int C);
 struct RvqEncArgs {
     const float *h;        // latent [dim][G][Lp]
     const float *wp_t;     // [2][dim][D]: transposed input_proj of the semantic, then the acoustic quantiser

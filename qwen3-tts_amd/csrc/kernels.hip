@@ -378,6 +378,7 @@ using detail::conv_gemm_launch_tn;
 
 const char *conv_gemm_kernel_name(const ConvGemmArgs &a) {
     if (a.wb) return conv_gemm_bf16_kernel_name(a);
+    if (gemm1_selected(a)) return gemm1_kernel_name(a);
     static char names[3][2][8][48];
     int tn = conv_gemm_launch_tn(a);
     int fuse = a.w2 ? 1 : 0, nw = conv_gemm_waves(a);
@@ -417,6 +418,7 @@ static hipError_t conv_gemm_launch_one(const ConvGemmArgs &a, int HL, int XW, in
 
 hipError_t launch_conv_gemm(const ConvGemmArgs &a_in, hipStream_t s) {
     if (a_in.wb) return launch_conv_gemm_bf16(a_in, s);
+    if (gemm1_selected(a_in)) return launch_gemm1(a_in, s);
     ConvGemmArgs a = a_in;
     {   // timing-only ablation switch (HIPVOC_DBG bit0: stage the activation tile only once; bit1: the weight tile only once; bit2: no barriers; bit3: main loop only).  Results are
         // WRONG with it set; never set in production.
@@ -554,8 +556,53 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float *x, float *y, 
         for (int c = sl; c < C; c += 8) y[(long)c * P + p] = w[c] * (x[(long)c * P + p] * r);
 }
 
+// Same workgroup shape, same slice assignment (channel c = slice + 8 j) and the same summation orders -- so the same
+// bits -- with the thread's C/8 channels held in registers: all loads are issued before the first use and x is read
+// once.  (The loop form above waits one memory latency per channel: 29 us per launch at C = 512, whatever the batch.)
+template <int NPT>
+__global__ __launch_bounds__(256) void rmsnorm_reg_kernel(const float *x, float *y, const float *w, int C, long P,
+                                                           float eps) {
+    __shared__ float red[8][32];
+    int lp = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    long p = (long)blockIdx.x * 32 + lp;
+    bool ok = p < P;
+    long pc = ok ? p : P - 1;
+    float v[NPT];
+#pragma unroll
+    for (int j = 0; j < NPT; j++) {
+        int c = sl + 8 * j;
+        v[j] = c < C ? x[(long)c * P + pc] : 0.0f;
+    }
+    float ss = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NPT; j++) ss += v[j] * v[j];
+    red[sl][lp] = ss;
+    __syncthreads();
+    float tot = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) tot += red[i][lp];
+    float r = 1.0f / sqrtf(tot / (float)C + eps);
+#pragma unroll
+    for (int j = 0; j < NPT; j++) {
+        int c = sl + 8 * j;
+        if (ok && c < C) y[(long)c * P + p] = w[c] * (v[j] * r);
+    }
+}
+
+const char *rmsnorm_kernel_name(int C) {
+    return C <= 64 ? "rmsnorm_reg_kernel<8>" : C <= 256 ? "rmsnorm_reg_kernel<32>" : C <= 512 ? "rmsnorm_reg_kernel<64>"
+           : C <= 1024 ? "rmsnorm_reg_kernel<128>" : "rmsnorm_kernel";
+}
+
 hipError_t launch_rmsnorm(const float *x, float *y, const float *w, int C, long P, float eps, hipStream_t s) {
     if (P <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((P + 31) / 32));
+#define RN(N_) { hipLaunchKernelGGL(rmsnorm_reg_kernel<N_>, grid, dim3(256), 0, s, x, y, w, C, P, eps); return hipGetLastError(); }
+    if (C <= 64) RN(8)
+    if (C <= 256) RN(32)
+    if (C <= 512) RN(64)
+    if (C <= 1024) RN(128)
+#undef RN
     hipLaunchKernelGGL(rmsnorm_kernel, dim3((unsigned)((P + 31) / 32)), dim3(256), 0, s, x, y, w, C, P, eps);
     return hipGetLastError();
 }
@@ -905,9 +952,80 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(const float *x, float *y
         }
 }
 
+// Register-resident form (same slices, same orders, same bits): the conv outputs of the thread's C/8 channels stay in
+// registers between the three passes, y is written once and never re-read.
+template <int NPT, int K>
+__global__ __launch_bounds__(256) void dwconv_ln_reg_kernel(const float *x, float *y, const float *dw_w,
+                                                             const float *dw_b, const float *ln_w, const float *ln_b,
+                                                             int C, int G, int L, int Lp, float eps) {
+    __shared__ float red[8][32];
+    int lp = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    int t = blockIdx.x * 32 + lp;
+    int u = blockIdx.y;
+    bool ok = t < L;
+    int tc = ok ? t : L - 1;
+    long cs = (long)G * Lp, base = (long)u * Lp + t;
+    float v[NPT];
+    float sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NPT; j++) {
+        int c = sl + 8 * j;
+        float acc = 0.0f;
+        if (c < C) {
+            acc = dw_b[c];
+            const float *xr = x + (long)c * cs + (long)u * Lp;
+#pragma unroll
+            for (int q = 0; q < K; q++) {
+                int sidx = tc - (K - 1 - q);
+                if (sidx >= 0) acc += dw_w[c * K + q] * xr[sidx];
+            }
+        }
+        v[j] = acc;
+    }
+#pragma unroll
+    for (int j = 0; j < NPT; j++) sum += v[j];
+    red[sl][lp] = sum;
+    __syncthreads();
+    float mean = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) mean += red[i][lp];
+    mean /= (float)C;
+    __syncthreads();
+    float var = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NPT; j++) {
+        float d = v[j] - mean;
+        var += (sl + 8 * j < C) ? d * d : 0.0f;
+    }
+    red[sl][lp] = var;
+    __syncthreads();
+    float vt = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) vt += red[i][lp];
+    float r = 1.0f / sqrtf(vt / (float)C + eps);
+#pragma unroll
+    for (int j = 0; j < NPT; j++) {
+        int c = sl + 8 * j;
+        if (ok && c < C) y[(long)c * cs + base] = (v[j] - mean) * r * ln_w[c] + ln_b[c];
+    }
+}
+
+const char *dwconv_ln_kernel_name(int C, int K) {
+    if (K != 7 || C > 1024) return "dwconv_ln_kernel";
+    return C <= 64 ? "dwconv_ln_reg_kernel<8,7>" : C <= 512 ? "dwconv_ln_reg_kernel<64,7>" : "dwconv_ln_reg_kernel<128,7>";
+}
+
 hipError_t launch_dwconv_ln(const float *x, float *y, const float *dw_w, const float *dw_b, const float *ln_w,
                             const float *ln_b, int C, int K, int G, int L, int Lp, float eps, hipStream_t s) {
     if (G <= 0 || L <= 0) return hipSuccess;
+    if (K == 7 && C <= 1024) {
+        const dim3 grid((L + 31) / 32, G);
+#define DL(N_) { hipLaunchKernelGGL((dwconv_ln_reg_kernel<N_, 7>), grid, dim3(256), 0, s, x, y, dw_w, dw_b, ln_w, ln_b, C, G, L, Lp, eps); return hipGetLastError(); }
+        if (C <= 64) DL(8)
+        if (C <= 512) DL(64)
+        DL(128)
+#undef DL
+    }
     hipLaunchKernelGGL(dwconv_ln_kernel, dim3((L + 31) / 32, G), dim3(256), 0, s, x, y, dw_w, dw_b, ln_w, ln_b, C, K,
                        G, L, Lp, eps);
     return hipGetLastError();

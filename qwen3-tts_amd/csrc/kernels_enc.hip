@@ -95,8 +95,64 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *x, float *y
         for (int c = sl; c < C; c += 8) y[(long)c * P + p] = (x[(long)c * P + p] - mean) / den * w[c] + b[c];
 }
 
+// Register-resident form: same slices and summation orders (the same bits), x read once, all loads in flight together.
+template <int NPT>
+__global__ __launch_bounds__(256) void layernorm_reg_kernel(const float *x, float *y, const float *w, const float *b,
+                                                             int C, long P, float eps) {
+    __shared__ float red[8][32];
+    int lp = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    long p = (long)blockIdx.x * 32 + lp;
+    bool ok = p < P;
+    long pc = ok ? p : P - 1;
+    float v[NPT];
+#pragma unroll
+    for (int j = 0; j < NPT; j++) {
+        int c = sl + 8 * j;
+        v[j] = c < C ? x[(long)c * P + pc] : 0.0f;
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NPT; j++) s += v[j];
+    red[sl][lp] = s;
+    __syncthreads();
+    float mean = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) mean += red[i][lp];
+    mean /= (float)C;
+    __syncthreads();
+    float q = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NPT; j++) {
+        float d = v[j] - mean;
+        q += (sl + 8 * j < C) ? d * d : 0.0f;
+    }
+    red[sl][lp] = q;
+    __syncthreads();
+    float var = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) var += red[i][lp];
+    float den = sqrtf(var / (float)C + eps);
+#pragma unroll
+    for (int j = 0; j < NPT; j++) {
+        int c = sl + 8 * j;
+        if (ok && c < C) y[(long)c * P + p] = (v[j] - mean) / den * w[c] + b[c];
+    }
+}
+
+const char *layernorm_kernel_name(int C) {
+    return C <= 64 ? "layernorm_reg_kernel<8>" : C <= 512 ? "layernorm_reg_kernel<64>" : C <= 1024 ? "layernorm_reg_kernel<128>" : "layernorm_kernel";
+}
+
 hipError_t launch_layernorm(const float *x, float *y, const float *w, const float *b, int C, long P, float eps, hipStream_t s) {
     if (P <= 0) return hipSuccess;
+    {
+        const dim3 grid((unsigned)((P + 31) / 32));
+#define LN(N_) { hipLaunchKernelGGL(layernorm_reg_kernel<N_>, grid, dim3(256), 0, s, x, y, w, b, C, P, eps); return hipGetLastError(); }
+        if (C <= 64) LN(8)
+        if (C <= 512) LN(64)
+        if (C <= 1024) LN(128)
+#undef LN
+    }
     hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((P + 31) / 32)), dim3(256), 0, s, x, y, w, b, C, P, eps);
     return hipGetLastError();
 }

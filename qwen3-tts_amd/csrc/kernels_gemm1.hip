@@ -1,0 +1,414 @@
+// gfx950 (CDNA4 / MI355X): the 1-tap GEMMs of the path (transformer projections, ConvNeXt pointwise convs) when the
+// launch is SMALL -- a single utterance (BASELINE configs[1]) or a few units.
+//
+// conv_gemm_kernel (kernels.hip) stages 16 input channels per barrier and prefetches one stage ahead: right when
+// several workgroups share a CU and hide each other's memory latency, wrong when the whole launch is a few dozen
+// workgroups -- then every one of the K/16 stages waits a full L2/HBM round trip (1.4 us measured; o_proj with
+// K = 1024 took 90 us at ANY batch size up to 64 units).  This kernel makes the same products with 64 input channels
+// per stage (a quarter of the round trips, 32 MFMAs per tile and wave between barriers) and 128 positions per
+// workgroup (4 waves: twice the workgroups on a small launch).
+//
+// Same v_mfma_f32_32x32x2_f32 chain per output element, k ascending in the same (2kk + h) pairs, the same epilogue
+// (device_common.h): the results are bit-identical to conv_gemm_kernel's, so which of the two runs may depend on the
+// launch size without breaking batch == single (tests/test_gpu_parity.py, test_gemm1_bitwise).
+#include "kernels.h"
+#include "device_common.h"
+
+#include <cstdio>
+#include <cstdlib>
+
+namespace hipvoc {
+
+static constexpr int G1_BK = 64;     // input channels per stage
+static constexpr int G1_BM = 128;    // positions per workgroup (4 waves x 32)
+static constexpr int G1_NTH = 256;
+
+template <int TN, bool ENC>
+__global__ __launch_bounds__(G1_NTH, 2) void gemm1_kernel(ConvGemmArgs a, int tiles_per_unit, int n_tiles) {
+    constexpr int BN = TN * 32;
+    constexpr int XP = G1_BK * (G1_BM / 4) / G1_NTH;   // float4 of X per thread and stage: 8
+    constexpr int WP = G1_BK * (BN / 4) / G1_NTH;      // float4 of W per thread and stage: 2 TN
+    extern __shared__ __attribute__((aligned(16))) float smem_all[];
+    float *Pm = smem_all;                               // [4][BN] parameter table
+    float *Xs = smem_all + 4 * BN;                      // [2][64][128]
+    float *Ws = Xs + 2 * G1_BK * G1_BM;                 // [2][64][BN]
+
+    int nwg = gridDim.x, orig = blockIdx.x;             // XCD-aware remap, as conv_gemm_kernel
+    int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+    int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    int nt = id % n_tiles;
+    int pt = id / n_tiles;
+    int unit = pt / tiles_per_unit;
+    int m0 = (pt - unit * tiles_per_unit) * G1_BM;
+    int n0 = nt * BN;
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const float *xu = a.x + (long)unit * a.x_us;
+    const int CinP = ((a.Cin + 31) / 32) * 32;          // rows of the packed weight tensor
+    const int nch = (a.Cin + G1_BK - 1) / G1_BK;
+
+    fill_param_table<BN, false>(a, Pm, n0, tid, G1_NTH);
+
+    f32x16 acc[TN];
+#pragma unroll
+    for (int i = 0; i < TN; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][r] = 0.0f;
+
+    // X piece j of this thread: row (tid >> 5) + 8 j of the stage, float4 column tid & 31.  Loads are unconditional
+    // from clamped addresses; rows >= Cin and positions >= Lin are zeroed at commit.
+    const int c4 = tid & 31, xr0 = tid >> 5;
+    const int xlim = ((a.Lin + 3) & ~3) - 4;
+    const int pos = m0 + 4 * c4;
+    const int posc = pos > xlim ? xlim : pos;
+    // W piece j: float4 index tid + 256 j of the [64][BN] tile
+    constexpr int WC4 = BN / 4;
+    float4 xr[XP], wr[WP];
+    auto fetch = [&](int ch) {
+#pragma unroll
+        for (int j = 0; j < XP; j++) {
+            int row = ch * G1_BK + xr0 + 8 * j;
+            row = row < a.Cin ? row : 0;
+            xr[j] = *reinterpret_cast<const float4 *>(xu + (long)row * a.x_cs + posc);
+        }
+#pragma unroll
+        for (int j = 0; j < WP; j++) {
+            const int q = tid + G1_NTH * j;
+            int row = ch * G1_BK + q / WC4;
+            row = row < CinP ? row : 0;
+            wr[j] = *reinterpret_cast<const float4 *>(a.w + (long)row * a.NP + n0 + (q % WC4) * 4);
+        }
+    };
+    auto commit = [&](int ch, int buf) {
+#pragma unroll
+        for (int j = 0; j < XP; j++) {
+            const int row = ch * G1_BK + xr0 + 8 * j;
+            const bool ok = row < a.Cin;
+            float4 v = xr[j];
+            v.x = ok && pos + 0 < a.Lin ? v.x : 0.0f;
+            v.y = ok && pos + 1 < a.Lin ? v.y : 0.0f;
+            v.z = ok && pos + 2 < a.Lin ? v.z : 0.0f;
+            v.w = ok && pos + 3 < a.Lin ? v.w : 0.0f;
+            *reinterpret_cast<float4 *>(Xs + (buf * G1_BK + xr0 + 8 * j) * G1_BM + c4 * 4) = v;
+        }
+#pragma unroll
+        for (int j = 0; j < WP; j++) {
+            const int q = tid + G1_NTH * j;
+            const bool ok = ch * G1_BK + q / WC4 < CinP;
+            float4 v = wr[j];
+            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4 *>(Ws + buf * G1_BK * BN + q * 4) = v;
+        }
+    };
+
+    fetch(0);
+    commit(0, 0);
+    for (int ch = 0; ch < nch; ch++) {
+        // unconditional (the last stage re-fetches itself into the idle buffer): see conv_gemm_kernel
+        const int nx = ch + 1 < nch ? ch + 1 : ch;
+        fetch(nx);
+        __syncthreads();                                 // stage ch visible; the readers of the other buffer are past
+        {
+            // LDS reads run one batch of eight k-pairs ahead of the MFMAs (a small launch has ONE wave per SIMD: nothing
+            // else hides the ds_read latency), and the commit below must not be hoisted into the MFMAs -- it waits for
+            // the global loads of the next stage, whose latency the MFMAs are there to cover.
+            const float *ws = Ws + (ch & 1) * G1_BK * BN + l31;
+            const float *xs = Xs + (ch & 1) * G1_BK * G1_BM + wave * 32 + l31;
+            constexpr int KB = 8, NB = G1_BK / 2 / KB;
+            float av[2][KB][TN], bv[2][KB];
+            auto lds_batch = [&](int b, int sl) {
+#pragma unroll
+                for (int q = 0; q < KB; q++) {
+                    const int k = 2 * (b * KB + q) + h;
+                    bv[sl][q] = xs[k * G1_BM];
+#pragma unroll
+                    for (int i = 0; i < TN; i++) av[sl][q][i] = ws[k * BN + i * 32];
+                }
+            };
+            lds_batch(0, 0);
+#pragma unroll
+            for (int b = 0; b < NB; b++) {
+                if (b + 1 < NB) lds_batch(b + 1, (b + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < KB; q++)
+#pragma unroll
+                    for (int i = 0; i < TN; i++)
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[b & 1][q][i], bv[b & 1][q], acc[i], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        commit(nx, (ch + 1) & 1);
+    }
+
+    float *yu = a.y + (long)unit * a.y_us;
+    const float *ru0 = launder_after(a.res, acc[TN - 1][15]);
+    const float *ru = ru0 ? ru0 + (long)unit * a.y_us : nullptr;
+    float *y2u0 = launder_after(a.y2, acc[TN - 1][15]);
+    float *y2u = y2u0 ? y2u0 + (long)unit * a.y_us : nullptr;
+    const int m = m0 + wave * 32 + l31;
+#pragma unroll
+    for (int i = 0; i < TN; i++) conv_epilogue_tile<BN, ENC>(a, acc[i], Pm, n0, i * 32 + 4 * h, m, yu, ru, y2u);
+}
+
+// ---------------------------------------------------------------------------------------------------
+static bool g1_enc(const ConvGemmArgs &a) { return a.act == ACT_ELU || a.act == ACT_GELU_TANH; }
+
+// what the kernel supports: fp32, one tap at shift 0, stride-1 rows, no input activation, no fusion, no s2d
+static bool g1_supported(const ConvGemmArgs &a) {
+    return a.w && !a.wb && !a.w2 && !a.wb2 && !a.xb && !a.yb && a.ntaps == 1 && a.shift0 == 0 && a.S == 1 && !a.sn_a &&
+           !a.in_elu && a.s2d <= 1 && !(a.x_cs & 3) && !(a.x_us & 3) && !((uintptr_t)a.x & 15) && !((uintptr_t)a.w & 15) &&
+           a.TN >= 1 && a.TN <= 4 && !(a.NP % (32 * a.TN)) && a.NP >= a.N && a.Lin >= 1 && (!a.y2 || (a.psn_a && a.psn_ib));
+}
+
+static int g1_tn(const ConvGemmArgs &a) {
+    const long tiles_m = (long)((a.M + G1_BM - 1) / G1_BM) * a.units;
+    int tn = a.TN;
+    while (tn > 1 && tiles_m * (a.NP / (32 * tn)) < 512) {
+        int t2 = tn == 4 ? 2 : 1;
+        if (a.NP % (32 * t2)) break;
+        tn = t2;
+    }
+    return tn;
+}
+
+// Used when conv_gemm_kernel's own grid would be at most HIPVOC_GEMM1_WGS workgroups (0 disables the kernel).
+bool gemm1_selected(const ConvGemmArgs &a) {
+    const char *e = getenv("HIPVOC_GEMM1_WGS");      // read per call: a test toggles it between two handles
+    const int max_wgs = e ? atoi(e) : 384;
+    if (max_wgs <= 0 || !g1_supported(a)) return false;
+    const long tiles_m = (long)((a.M + 255) / 256) * a.units;
+    return tiles_m * (a.NP / (32 * detail::conv_gemm_launch_tn(a))) <= max_wgs;
+}
+
+const char *gemm1_kernel_name(const ConvGemmArgs &a) {
+    static char names[2][8][32];
+    const int tn = g1_tn(a), enc = g1_enc(a) ? 1 : 0;
+    char *n = names[enc][tn & 7];
+    if (!n[0]) snprintf(n, 32, "gemm1_kernel<%d,%s>", tn, enc ? "true" : "false");
+    return n;
+}
+
+template <int TN, bool ENC>
+static hipError_t gemm1_launch_one(const ConvGemmArgs &a, int tiles_per_unit, int n_tiles, long grid, size_t lds, hipStream_t s) {
+    static bool done[64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64 && !done[dev]) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm1_kernel<TN, ENC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        done[dev] = true;
+    }
+    hipLaunchKernelGGL((gemm1_kernel<TN, ENC>), dim3((unsigned)grid), dim3(G1_NTH), lds, s, a, tiles_per_unit, n_tiles);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm1(const ConvGemmArgs &a, hipStream_t s) {
+    if (a.M <= 0 || a.units <= 0) return hipSuccess;
+    if (!g1_supported(a)) return hipErrorInvalidValue;
+    const int tn = g1_tn(a);
+    const int tiles_per_unit = (a.M + G1_BM - 1) / G1_BM;
+    const int n_tiles = a.NP / (32 * tn);
+    const long grid = (long)tiles_per_unit * a.units * n_tiles;
+    if (grid > 0x7fffffffL) return hipErrorInvalidValue;
+    const size_t lds = sizeof(float) * (4 * 32 * (size_t)tn + 2 * G1_BK * (G1_BM + 32 * (size_t)tn));
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+#define G1(TN_)                                                                                         \
+    return g1_enc(a) ? gemm1_launch_one<TN_, true>(a, tiles_per_unit, n_tiles, grid, lds, s)            \
+                     : gemm1_launch_one<TN_, false>(a, tiles_per_unit, n_tiles, grid, lds, s)
+    switch (tn) {
+        case 1: G1(1);
+        case 2: G1(2);
+        case 3: G1(3);
+        default: G1(4);
+    }
+#undef G1
+}
+
+// ===================================================================================================
+// bf16 mode (conv_gemm_bf16_kernel's small-launch form): 128 input channels per stage -- eight
+// v_mfma_f32_32x32x16_bf16 per tile between barriers instead of two -- from the same operands in the same order
+// (k-groups ascending, lane half h supplies group 2s + h), so again bit-identical.  Activations are the channel-first
+// fp32 tensor (gathered eight channels at a time, rounded RNE at commit, as the XB = false form of the big kernel).
+// ===================================================================================================
+typedef __bf16 g1_bf16x8 __attribute__((ext_vector_type(8)));
+
+static constexpr int G1B_KG = 16;    // k-groups (of 8 channels) per stage
+
+template <int TN>
+__global__ __launch_bounds__(G1_NTH, 2) void gemm1_bf16_kernel(ConvGemmArgs a, int tiles_per_unit, int n_tiles) {
+    constexpr int BN = TN * 32;
+    constexpr int XP = G1B_KG * G1_BM / G1_NTH;         // (k-group, position) pairs per thread and stage: 8
+    constexpr int WP = G1B_KG * BN / G1_NTH;            // 16-byte weight elements per thread and stage: 2 TN
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw_all[];
+    float *Pm = reinterpret_cast<float *>(smem_raw_all);                   // [4][BN]
+    uint4 *Xs = reinterpret_cast<uint4 *>(smem_raw_all + 16 * BN);         // [2][16][128]
+    uint4 *Ws = Xs + 2 * G1B_KG * G1_BM;                                   // [2][16][BN]
+
+    int nwg = gridDim.x, orig = blockIdx.x;
+    int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+    int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    int nt = id % n_tiles;
+    int pt = id / n_tiles;
+    int unit = pt / tiles_per_unit;
+    int m0 = (pt - unit * tiles_per_unit) * G1_BM;
+    int n0 = nt * BN;
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const float *xu = a.x + (long)unit * a.x_us;
+    const int ngr = ((a.Cin + 31) / 32) * 4;            // k-groups of the packed weight tensor
+    const int nch = (a.Cin + 8 * G1B_KG - 1) / (8 * G1B_KG);
+
+    fill_param_table<BN, false>(a, Pm, n0, tid, G1_NTH);
+
+    f32x16 acc[TN];
+#pragma unroll
+    for (int i = 0; i < TN; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][r] = 0.0f;
+
+    // pair j of this thread: k-group (tid >> 7) + 2 j of the stage, position tid & 127
+    const int t = tid & 127, kg0 = tid >> 7;
+    const int pos = m0 + t;
+    const bool pos_ok = pos < a.Lin;
+    const int posc = pos_ok ? pos : a.Lin - 1;
+    const uint4 *wg = reinterpret_cast<const uint4 *>(a.wb);
+    float xr[XP][8];
+    uint4 wr[WP];
+    auto fetch = [&](int ch) {
+#pragma unroll
+        for (int j = 0; j < XP; j++) {
+            const int c0 = (ch * G1B_KG + kg0 + 2 * j) * 8;
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                int row = c0 + c;
+                row = row < a.Cin ? row : 0;
+                xr[j][c] = xu[(long)row * a.x_cs + posc];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < WP; j++) {
+            const int q = tid + G1_NTH * j;
+            int g = ch * G1B_KG + q / BN;
+            g = g < ngr ? g : 0;
+            wr[j] = wg[(long)g * a.NP + n0 + q % BN];
+        }
+    };
+    auto commit = [&](int ch, int buf) {
+#pragma unroll
+        for (int j = 0; j < XP; j++) {
+            const int c0 = (ch * G1B_KG + kg0 + 2 * j) * 8;
+            g1_bf16x8 o;
+#pragma unroll
+            for (int c = 0; c < 8; c++) o[c] = (__bf16)((pos_ok && c0 + c < a.Cin) ? xr[j][c] : 0.0f);
+            Xs[(buf * G1B_KG + kg0 + 2 * j) * G1_BM + t] = __builtin_bit_cast(uint4, o);
+        }
+#pragma unroll
+        for (int j = 0; j < WP; j++) {
+            const int q = tid + G1_NTH * j;
+            uint4 v = wr[j];
+            if (ch * G1B_KG + q / BN >= ngr) v = make_uint4(0, 0, 0, 0);
+            Ws[buf * G1B_KG * BN + q] = v;
+        }
+    };
+
+    fetch(0);
+    commit(0, 0);
+    for (int ch = 0; ch < nch; ch++) {
+        const int nx = ch + 1 < nch ? ch + 1 : ch;
+        fetch(nx);
+        __syncthreads();
+        {
+            const g1_bf16x8 *wsb = reinterpret_cast<const g1_bf16x8 *>(Ws) + (ch & 1) * G1B_KG * BN + l31;
+            const g1_bf16x8 *xsb = reinterpret_cast<const g1_bf16x8 *>(Xs) + (ch & 1) * G1B_KG * G1_BM + wave * 32 + l31;
+            g1_bf16x8 av[G1B_KG / 2][TN], bv[G1B_KG / 2];
+#pragma unroll
+            for (int sp = 0; sp < G1B_KG / 2; sp++) {
+                const int kq = 2 * sp + h;
+                bv[sp] = xsb[kq * G1_BM];
+#pragma unroll
+                for (int i = 0; i < TN; i++) av[sp][i] = wsb[kq * BN + i * 32];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int sp = 0; sp < G1B_KG / 2; sp++)
+#pragma unroll
+                for (int i = 0; i < TN; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[sp][i], bv[sp], acc[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        commit(nx, (ch + 1) & 1);
+    }
+
+    float *yu = a.y + (long)unit * a.y_us;
+    const float *ru0 = launder_after(a.res, acc[TN - 1][15]);
+    const float *ru = ru0 ? ru0 + (long)unit * a.y_us : nullptr;
+    float *y2u0 = launder_after(a.y2, acc[TN - 1][15]);
+    float *y2u = y2u0 ? y2u0 + (long)unit * a.y_us : nullptr;
+    const int m = m0 + wave * 32 + l31;
+#pragma unroll
+    for (int i = 0; i < TN; i++) conv_epilogue_tile<BN>(a, acc[i], Pm, n0, i * 32 + 4 * h, m, yu, ru, y2u);
+}
+
+static bool g1b_supported(const ConvGemmArgs &a) {
+    return a.wb && !a.wb2 && !a.w2 && !a.xb && !a.yb && a.y && a.ntaps == 1 && a.shift0 == 0 && a.S == 1 && !a.sn_a &&
+           !a.in_elu && a.s2d <= 1 && !((uintptr_t)a.wb & 15) && a.TN >= 1 && a.TN <= 4 && !(a.NP % (32 * a.TN)) &&
+           a.NP >= a.N && a.Lin >= 1 && a.act != ACT_ELU && a.act != ACT_GELU_TANH && (!a.y2 || (a.psn_a && a.psn_ib));
+}
+
+bool gemm1_bf16_selected(const ConvGemmArgs &a) {
+    const char *e = getenv("HIPVOC_GEMM1_WGS");
+    const int max_wgs = e ? atoi(e) : 384;
+    if (max_wgs <= 0 || !g1b_supported(a)) return false;
+    const long tiles_m = (long)((a.M + 255) / 256) * a.units;
+    return tiles_m * (a.NP / (32 * detail::conv_gemm_launch_tn(a))) <= max_wgs;
+}
+
+// tiles of at most 64 rows: the whole stage's operands sit in registers ahead of the MFMAs
+static int g1b_tn(const ConvGemmArgs &a) {
+    const int tn = g1_tn(a);
+    return tn <= 2 ? tn : (a.NP % 64 ? 1 : 2);
+}
+
+const char *gemm1_bf16_kernel_name(const ConvGemmArgs &a) {
+    static char names[8][32];
+    const int tn = g1b_tn(a);
+    char *n = names[tn & 7];
+    if (!n[0]) snprintf(n, 32, "gemm1_bf16_kernel<%d>", tn);
+    return n;
+}
+
+template <int TN>
+static hipError_t gemm1_bf16_launch_one(const ConvGemmArgs &a, int tiles_per_unit, int n_tiles, long grid, size_t lds, hipStream_t s) {
+    static bool done[64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64 && !done[dev]) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm1_bf16_kernel<TN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        done[dev] = true;
+    }
+    hipLaunchKernelGGL((gemm1_bf16_kernel<TN>), dim3((unsigned)grid), dim3(G1_NTH), lds, s, a, tiles_per_unit, n_tiles);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm1_bf16(const ConvGemmArgs &a, hipStream_t s) {
+    if (a.M <= 0 || a.units <= 0) return hipSuccess;
+    if (!g1b_supported(a)) return hipErrorInvalidValue;
+    const int tn = g1b_tn(a);
+    const int tiles_per_unit = (a.M + G1_BM - 1) / G1_BM;
+    const int n_tiles = a.NP / (32 * tn);
+    const long grid = (long)tiles_per_unit * a.units * n_tiles;
+    if (grid > 0x7fffffffL) return hipErrorInvalidValue;
+    const size_t lds = 16 * 32 * (size_t)tn + 16 * 2 * G1B_KG * (G1_BM + 32 * (size_t)tn);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    switch (tn) {
+        case 1: return gemm1_bf16_launch_one<1>(a, tiles_per_unit, n_tiles, grid, lds, s);
+        default: return gemm1_bf16_launch_one<2>(a, tiles_per_unit, n_tiles, grid, lds, s);
+    }
+}
+
+}  // namespace hipvoc

@@ -181,3 +181,24 @@ def test_channel_counts_that_pad_the_row_tiles(pkg, synth, vo):
         assert g.shape == rb.shape and snr_db(rb, g) >= 30.0, (s, snr_db(rb, g))
     gb = vb.synthesize(codes)
     assert snr_db(ref, gb) >= WAV_SNR_DB and np.abs(gb - ref).max() <= WAV_MAX_ABS
+
+
+@pytest.mark.parametrize("cfg_name,unit,frames", [("FULL", 64, 125), ("ODD", 9, 20), ("SMALL", 8, 13)])
+def test_bf16_gemm1_bitwise(pkg, synth, cfg_name, unit, frames, monkeypatch):
+    """bf16 mode: the small-launch 1-tap GEMM kernel (gemm1_bf16_kernel, 128 channels per stage) against
+    conv_gemm_bf16_kernel on the same inputs -- the same MFMA chains, so the same bits."""
+    cfg = getattr(synth, cfg_name)
+    path = os.path.join(tempfile.gettempdir(), f"hipvoc_test_{cfg_name}_0.safetensors")
+    if not os.path.exists(path):
+        synth.save_safetensors(path, synth.make_weights(cfg, 0), cfg.metadata())
+    codes = synth.make_codes(frames, 31, cfg)
+    outs = []
+    for wgs in ("0", "1000000"):
+        monkeypatch.setenv("HIPVOC_GEMM1_WGS", wgs)
+        v = pkg.HipVocoder.load(path, device=0, unit_frames=unit, dtype=1)
+        v.set_profile(True)
+        outs.append(v.synthesize(codes))
+        used = any("gemm1_bf16_kernel" in k for k in v.last_profile())
+        assert used == (wgs != "0"), (wgs, sorted(v.last_profile()))
+        del v
+    assert outs[0].size and np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))

@@ -304,3 +304,24 @@ def test_right_only_transconv_trim_policy(pkg, synth, vo):
     gb = vb.synthesize(c)
     assert gb.size == 10 * 1920
     assert snr_db(o.synthesize(c, 4), gb) >= 30.0 and snr_db(ob.synthesize(c, 4), gb) >= 30.0
+
+
+@pytest.mark.parametrize("cfg_name,unit,frames", [("FULL", 64, 125), ("ODD", 9, 20), ("SMALL", 8, 13)])
+def test_gemm1_bitwise(pkg, synth, cfg_name, unit, frames, monkeypatch):
+    """The small-launch form of the 1-tap GEMMs (kernels_gemm1.hip: 64 channels per stage, 128 positions per workgroup)
+    makes the same MFMA chains as conv_gemm_kernel: with it disabled (HIPVOC_GEMM1_WGS=0) the waveform is the same,
+    bit for bit -- which is what lets the choice depend on the launch size."""
+    cfg = getattr(synth, cfg_name)
+    voc_for(pkg, synth, cfg_name, 0, unit)                      # makes the checkpoint file
+    path = os.path.join(tempfile.gettempdir(), f"hipvoc_test_{cfg_name}_0.safetensors")
+    codes = synth.make_codes(frames, 31, cfg)
+    outs = []
+    for wgs in ("0", "1000000"):
+        monkeypatch.setenv("HIPVOC_GEMM1_WGS", wgs)
+        v = pkg.HipVocoder.load(path, device=0, unit_frames=unit)
+        v.set_profile(True)
+        outs.append(v.synthesize(codes))
+        used = any("gemm1_kernel" in k for k in v.last_profile())
+        assert used == (wgs != "0"), (wgs, sorted(v.last_profile()))
+        del v
+    assert outs[0].size and np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))

@@ -25,4 +25,6 @@ for dtype in (0, 1):
     prof = v.last_profile()
     v.set_profile(False)
     dev = sum(x[0] for x in prof.values()); n = sum(x[2] for x in prof.values())
+    for k, (ms, fl, ln) in sorted(prof.items(), key=lambda kv: -kv[1][0]):
+        print(f"    {k:58s} {ms:7.3f} ms {100*ms/dev:5.1f}%  {fl/ms/1e9 if ms > 0 else 0:7.1f} TFLOP/s  x{ln}")
     print(f"dtype={dtype}: latency median {1e3*np.median(ts):.2f} ms, min {1e3*min(ts):.2f}; event-to-event device time {dev:.2f} ms over {n} launches")
