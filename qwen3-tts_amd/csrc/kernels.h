@@ -70,6 +70,9 @@ hipError_t launch_conv_gemm_bf16(const ConvGemmArgs &a, hipStream_t s);
 bool gemm1_selected(const ConvGemmArgs &a);
 hipError_t launch_gemm1(const ConvGemmArgs &a, hipStream_t s);
 const char *gemm1_kernel_name(const ConvGemmArgs &a);
+bool convs_selected(const ConvGemmArgs &a);           // multi-tap convs on a small launch (fp32)
+hipError_t launch_convs(const ConvGemmArgs &a, hipStream_t s);
+const char *convs_kernel_name(const ConvGemmArgs &a);
 bool gemm1_bf16_selected(const ConvGemmArgs &a);      // the same for the bf16 mode (launch_conv_gemm_bf16 dispatches)
 hipError_t launch_gemm1_bf16(const ConvGemmArgs &a, hipStream_t s);
 const char *gemm1_bf16_kernel_name(const ConvGemmArgs &a);

@@ -228,6 +228,257 @@ hipError_t launch_gemm1(const ConvGemmArgs &a, hipStream_t s) {
 }
 
 // ===================================================================================================
+// Multi-tap convs (conv7 of the decoder blocks, transposed convs, pre_conv) on a small launch.  conv_gemm_kernel
+// stages ONE tap's 16 x BN weight tile per barrier, one stage ahead: 8 TN MFMAs (0.2 TN us) against a 1.4 us memory
+// round trip -- fine under the other workgroups of a busy CU, 470 us for b0's conv7 (336 stages) when the launch is
+// a few hundred workgroups.  Here a stage is a channel block of 16 with ALL its taps (conv7: 56 TN MFMAs per barrier),
+// 128 positions per workgroup, and the products are made in conv_gemm_kernel's order (channel block, tap, k pair),
+// so the results are bit-identical.  (The CB = 4 form for the 2-tap transposed convs was measured: 1.1-2.1x SLOWER than
+// conv_gemm_kernel on a single utterance -- their N = channels x stride makes many row tiles re-read X -- and is not
+// instantiated.)
+// ===================================================================================================
+template <int TN, int CB>
+__global__ __launch_bounds__(G1_NTH, (CB == 1 && TN == 1) ? 3 : 2) void convs_kernel(ConvGemmArgs a, int HL, int XW, int tiles_per_unit, int n_tiles) {
+    constexpr int BN = TN * 32;
+    constexpr int KR = CB * 16;                         // input channels per stage
+    constexpr int XPM = CB == 1 ? 4 : 10;               // float4 of X per thread and stage (host checks the fit)
+    constexpr int WPM = 4 * TN;                         // float4 of W per thread and stage: CB * ntaps <= 8 slabs of [16][BN]
+    extern __shared__ __attribute__((aligned(16))) float smem_all[];
+    float *Pm = smem_all;
+    float *Xs = smem_all + 4 * BN;                      // [2][KR][XW]
+    const int xtile = KR * XW;
+    const int slabs = CB * a.ntaps;
+    const int wtile = slabs * 16 * BN;
+    float *Ws = Xs + 2 * xtile;                         // [2][slabs][16][BN]
+
+    int nwg = gridDim.x, orig = blockIdx.x;
+    int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+    int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    int nt = id % n_tiles;
+    int pt = id / n_tiles;
+    int unit = pt / tiles_per_unit;
+    int m0 = (pt - unit * tiles_per_unit) * G1_BM;
+    int n0 = nt * BN;
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const float *xu = a.x + (long)unit * a.x_us;
+    const int CinP = ((a.Cin + 31) / 32) * 32;
+    const int nst = (a.Cin + KR - 1) / KR;
+    const int xw4 = XW >> 2;
+    const int xlim = ((a.Lin + 3) & ~3) - 4;
+
+    fill_param_table<BN, false>(a, Pm, n0, tid, G1_NTH);
+
+    f32x16 acc[TN];
+#pragma unroll
+    for (int i = 0; i < TN; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][r] = 0.0f;
+
+    // ---- per-thread piece geometry (loop-invariant)
+    int xk[XPM], xps[XPM];                              // stage row (or -1: no such piece), unclamped position
+    unsigned xoff[XPM];
+#pragma unroll
+    for (int j = 0; j < XPM; j++) {
+        const int p = tid + G1_NTH * j;
+        const int row = p / xw4, c4 = p - row * xw4;
+        const bool ex = row < KR;
+        int pos = m0 - HL + 4 * c4;
+        xk[j] = ex ? row : -1;
+        xps[j] = pos;
+        pos = pos < 0 ? 0 : (pos > xlim ? xlim : pos);
+        xoff[j] = (unsigned)(ex ? row : 0) * (unsigned)a.x_cs + (unsigned)pos;
+    }
+    int wrow[WPM], wk[WPM];                             // weight row within the tensor at stage 0; channel within the stage (or -1)
+#pragma unroll
+    for (int j = 0; j < WPM; j++) {
+        const int q = tid + G1_NTH * j;
+        const int slab = q / (4 * BN), rem = q - slab * (4 * BN);
+        const int k = rem / (BN / 4);
+        const bool ex = slab < slabs;
+        const int cbi = ex ? slab / a.ntaps : 0, tap = ex ? slab - cbi * a.ntaps : 0;
+        wk[j] = ex ? cbi * 16 + k : -1;
+        wrow[j] = tap * CinP + cbi * 16 + k;
+    }
+    float4 xr[XPM], wr[WPM];
+    float2 sp[XPM];
+    auto fetch = [&](int st) {
+        const bool full = (st + 1) * KR <= a.Cin;       // wave-uniform
+#pragma unroll
+        for (int j = 0; j < XPM; j++) {
+            int ci = st * KR + (xk[j] < 0 ? 0 : xk[j]);
+            if (full) {
+                xr[j] = *reinterpret_cast<const float4 *>(xu + (long)st * KR * a.x_cs + xoff[j]);
+            } else {
+                ci = ci < a.Cin ? ci : 0;
+                int pos = xps[j];
+                pos = pos < 0 ? 0 : (pos > xlim ? xlim : pos);
+                xr[j] = *reinterpret_cast<const float4 *>(xu + (long)ci * a.x_cs + pos);
+            }
+            ci = ci < a.Cin ? ci : 0;
+            sp[j] = a.sn_a ? make_float2(a.sn_a[ci], a.sn_ib[ci]) : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < WPM; j++) {
+            const int q = tid + G1_NTH * j;
+            const int rem = q % (4 * BN);
+            const bool ok = wk[j] >= 0 && st * KR + wk[j] < CinP;
+            const long row = ok ? (long)wrow[j] + (long)st * KR : 0;
+            wr[j] = *reinterpret_cast<const float4 *>(a.w + row * a.NP + n0 + (rem % (BN / 4)) * 4);
+        }
+    };
+    auto commit = [&](int st, int buf) {
+#pragma unroll
+        for (int j = 0; j < XPM; j++) {
+            if (xk[j] < 0) continue;
+            const int pos = xps[j];
+            const bool ok = st * KR + xk[j] < a.Cin && pos >= 0;     // pos is a multiple of 4
+            float4 v = xr[j];
+            v.x = ok && pos + 0 < a.Lin ? v.x : 0.0f;
+            v.y = ok && pos + 1 < a.Lin ? v.y : 0.0f;
+            v.z = ok && pos + 2 < a.Lin ? v.z : 0.0f;
+            v.w = ok && pos + 3 < a.Lin ? v.w : 0.0f;
+            if (a.sn_a) {
+                f32x2 lo = snake_beta2(mk2(v.x, v.y), (f32x2)(sp[j].x), (f32x2)(sp[j].y));
+                f32x2 hi = snake_beta2(mk2(v.z, v.w), (f32x2)(sp[j].x), (f32x2)(sp[j].y));
+                v = make_float4(lo.x, lo.y, hi.x, hi.y);
+            }
+            *reinterpret_cast<float4 *>(Xs + buf * xtile + (tid + G1_NTH * j) * 4) = v;
+        }
+#pragma unroll
+        for (int j = 0; j < WPM; j++) {
+            if (wk[j] < 0) continue;
+            float4 v = wr[j];
+            if (st * KR + wk[j] >= CinP) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4 *>(Ws + buf * wtile + (tid + G1_NTH * j) * 4) = v;
+        }
+    };
+
+    fetch(0);
+    commit(0, 0);
+    for (int st = 0; st < nst; st++) {
+        const int nx = st + 1 < nst ? st + 1 : st;
+        fetch(nx);
+        __syncthreads();
+        {
+            const float *wsb = Ws + (st & 1) * wtile + l31;
+            const float *xsb = Xs + (st & 1) * xtile + wave * 32 + l31 + HL + a.shift0;
+            float av[2][8][TN], bv[2][8];
+            auto lds_slab = [&](int sl, int set) {     // slab = (channel block, tap): eight k pairs
+                const int cbi = sl / a.ntaps, tap = sl - cbi * a.ntaps;
+                const float *ws = wsb + sl * 16 * BN;
+                const float *xs = xsb + cbi * 16 * XW + tap * a.shift_step;
+#pragma unroll
+                for (int kk = 0; kk < 8; kk++) {
+                    const int k = 2 * kk + h;
+                    bv[set][kk] = xs[k * XW];
+#pragma unroll
+                    for (int i = 0; i < TN; i++) av[set][kk][i] = ws[k * BN + i * 32];
+                }
+            };
+            lds_slab(0, 0);
+            for (int sl = 0; sl < slabs; sl += 2) {
+                lds_slab(sl + 1 < slabs ? sl + 1 : sl, 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kk = 0; kk < 8; kk++)
+#pragma unroll
+                    for (int i = 0; i < TN; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0][kk][i], bv[0][kk], acc[i], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (sl + 1 < slabs) {
+                    lds_slab(sl + 2 < slabs ? sl + 2 : sl + 1, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int kk = 0; kk < 8; kk++)
+#pragma unroll
+                        for (int i = 0; i < TN; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][kk][i], bv[1][kk], acc[i], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        commit(nx, (st + 1) & 1);
+    }
+
+    float *yu = a.y + (long)unit * a.y_us;
+    const float *ru0 = launder_after(a.res, acc[TN - 1][15]);
+    const float *ru = ru0 ? ru0 + (long)unit * a.y_us : nullptr;
+    float *y2u0 = launder_after(a.y2, acc[TN - 1][15]);
+    float *y2u = y2u0 ? y2u0 + (long)unit * a.y_us : nullptr;
+    const int m = m0 + wave * 32 + l31;
+#pragma unroll
+    for (int i = 0; i < TN; i++) conv_epilogue_tile<BN, false>(a, acc[i], Pm, n0, i * 32 + 4 * h, m, yu, ru, y2u);
+}
+
+static int convs_cb(const ConvGemmArgs &a) { return a.ntaps >= 5 ? 1 : 4; }
+static int convs_tn(const ConvGemmArgs &a) {       // CB = 4 keeps ten float4 of X in flight: one tile of 32 rows only
+    if (convs_cb(a) != 1) return 1;
+    const int tn = g1_tn(a);
+    return tn <= 2 ? tn : (a.NP % 64 ? 1 : 2);
+}
+
+static bool convs_supported(const ConvGemmArgs &a) {
+    if (!(a.w && !a.wb && !a.w2 && !a.wb2 && !a.xb && !a.yb && a.ntaps >= 5 && a.ntaps <= 8 && a.S >= 1 && !a.in_elu &&
+          a.s2d <= 1 && a.act != ACT_ELU && a.act != ACT_GELU_TANH && !(a.x_cs & 3) && !(a.x_us & 3) &&
+          !((uintptr_t)a.x & 15) && !((uintptr_t)a.w & 15) && a.TN >= 1 && a.TN <= 4 && !(a.NP % (32 * a.TN)) &&
+          a.NP >= a.N && a.Lin >= 1 && (!a.y2 || (a.psn_a && a.psn_ib))))
+        return false;
+    int HL, XW;
+    detail::conv_gemm_geometry(a, HL, XW, G1_BM);
+    const int cb = convs_cb(a);
+    if (cb * a.ntaps > 8) return false;                                   // W pieces: 4 TN float4 per thread
+    if (cb * 16 * (XW / 4) > G1_NTH * (cb == 1 ? 4 : 10)) return false;   // X pieces
+    return true;
+}
+
+bool convs_selected(const ConvGemmArgs &a) {
+    const char *e = getenv("HIPVOC_CONVS_WGS");
+    const int max_wgs = e ? atoi(e) : 384;
+    if (max_wgs <= 0 || !convs_supported(a)) return false;
+    const long tiles_m = (long)((a.M + 255) / 256) * a.units;
+    return tiles_m * (a.NP / (32 * detail::conv_gemm_launch_tn(a))) <= max_wgs;
+}
+
+const char *convs_kernel_name(const ConvGemmArgs &a) {
+    static char names[2][8][32];
+    const int tn = convs_tn(a), cb = convs_cb(a);
+    char *n = names[cb == 1 ? 0 : 1][tn & 7];
+    if (!n[0]) snprintf(n, 32, "convs_kernel<%d,%d>", tn, cb);
+    return n;
+}
+
+template <int TN, int CB>
+static hipError_t convs_launch_one(const ConvGemmArgs &a, int HL, int XW, int tiles_per_unit, int n_tiles, long grid, size_t lds, hipStream_t s) {
+    static bool done[64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64 && !done[dev]) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(convs_kernel<TN, CB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        done[dev] = true;
+    }
+    hipLaunchKernelGGL((convs_kernel<TN, CB>), dim3((unsigned)grid), dim3(G1_NTH), lds, s, a, HL, XW, tiles_per_unit, n_tiles);
+    return hipGetLastError();
+}
+
+hipError_t launch_convs(const ConvGemmArgs &a, hipStream_t s) {
+    if (a.M <= 0 || a.units <= 0) return hipSuccess;
+    if (!convs_supported(a)) return hipErrorInvalidValue;
+    int HL, XW;
+    detail::conv_gemm_geometry(a, HL, XW, G1_BM);
+    const int tn = convs_tn(a), cb = convs_cb(a);
+    const int tiles_per_unit = (a.M + G1_BM - 1) / G1_BM;
+    const int n_tiles = a.NP / (32 * tn);
+    const long grid = (long)tiles_per_unit * a.units * n_tiles;
+    if (grid > 0x7fffffffL) return hipErrorInvalidValue;
+    const size_t lds = sizeof(float) * (4 * 32 * (size_t)tn + 2 * (size_t)cb * 16 * XW + 2 * (size_t)cb * a.ntaps * 16 * 32 * tn);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    return tn == 1 ? convs_launch_one<1, 1>(a, HL, XW, tiles_per_unit, n_tiles, grid, lds, s)
+                   : convs_launch_one<2, 1>(a, HL, XW, tiles_per_unit, n_tiles, grid, lds, s);
+}
+
+// ===================================================================================================
 // bf16 mode (conv_gemm_bf16_kernel's small-launch form): 128 input channels per stage -- eight
 // v_mfma_f32_32x32x16_bf16 per tile between barriers instead of two -- from the same operands in the same order
 // (k-groups ascending, lane half h supplies group 2s + h), so again bit-identical.  Activations are the channel-first

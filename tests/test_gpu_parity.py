@@ -318,10 +318,12 @@ def test_gemm1_bitwise(pkg, synth, cfg_name, unit, frames, monkeypatch):
     outs = []
     for wgs in ("0", "1000000"):
         monkeypatch.setenv("HIPVOC_GEMM1_WGS", wgs)
+        monkeypatch.setenv("HIPVOC_CONVS_WGS", wgs)             # and of the multi-tap convs (convs_kernel)
         v = pkg.HipVocoder.load(path, device=0, unit_frames=unit)
         v.set_profile(True)
         outs.append(v.synthesize(codes))
-        used = any("gemm1_kernel" in k for k in v.last_profile())
-        assert used == (wgs != "0"), (wgs, sorted(v.last_profile()))
+        for name in ("gemm1_kernel", "convs_kernel<"):
+            used = any(name in k for k in v.last_profile())
+            assert used == (wgs != "0"), (wgs, name, sorted(v.last_profile()))
         del v
     assert outs[0].size and np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
