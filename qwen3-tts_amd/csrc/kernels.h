@@ -76,6 +76,9 @@ const char *convs_kernel_name(const ConvGemmArgs &a);
 bool gemm1_bf16_selected(const ConvGemmArgs &a);      // the same for the bf16 mode (launch_conv_gemm_bf16 dispatches)
 hipError_t launch_gemm1_bf16(const ConvGemmArgs &a, hipStream_t s);
 const char *gemm1_bf16_kernel_name(const ConvGemmArgs &a);
+bool convs_bf16_selected(const ConvGemmArgs &a);      // conv7 on a small launch, bf16 mode
+hipError_t launch_convs_bf16(const ConvGemmArgs &a, hipStream_t s);
+const char *convs_bf16_kernel_name(const ConvGemmArgs &a);
 const char *conv_gemm_bf16_kernel_name(const ConvGemmArgs &a);
 size_t conv_gemm_bf16_lds_bytes(const ConvGemmArgs &a);
 namespace detail {

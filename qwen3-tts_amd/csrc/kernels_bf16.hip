@@ -356,6 +356,7 @@ size_t conv_gemm_bf16_lds_bytes(const ConvGemmArgs &a) {
 
 const char *conv_gemm_bf16_kernel_name(const ConvGemmArgs &a) {
     if (gemm1_bf16_selected(a)) return gemm1_bf16_kernel_name(a);
+    if (convs_bf16_selected(a)) return convs_bf16_kernel_name(a);
     static char names[2][2][8][56];
     int tn = detail::conv_gemm_launch_tn(a);
     int fuse = a.wb2 ? 1 : 0, xbf = a.xb ? 1 : 0;
@@ -384,6 +385,7 @@ static hipError_t launch_one_bf16(const ConvGemmArgs &a, int HL, int XW, int til
 
 hipError_t launch_conv_gemm_bf16(const ConvGemmArgs &a_in, hipStream_t s) {
     if (gemm1_bf16_selected(a_in)) return launch_gemm1_bf16(a_in, s);
+    if (convs_bf16_selected(a_in)) return launch_convs_bf16(a_in, s);
     ConvGemmArgs a = a_in;
     {
         static int dbg = -1;

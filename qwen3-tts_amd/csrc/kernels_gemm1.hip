@@ -662,4 +662,200 @@ hipError_t launch_gemm1_bf16(const ConvGemmArgs &a, hipStream_t s) {
     }
 }
 
+// ===================================================================================================
+// bf16 mode, conv7 on a small launch: conv_gemm_bf16_kernel's stage is one tap of 32 channels (2 TN MFMAs of 32
+// cycles against the same 1.4 us round trip: 107 us for b0's conv7 on one utterance).  Here a stage is 64 channels
+// with all their taps (28 MFMAs per tile), single-buffered in 52 KB of LDS so that three workgroups share a CU and
+// cover each other's waits; products in conv_gemm_bf16_kernel's order (channel block of 32, tap, k-group pair).
+// XB: packed bf16 input (ConvGemmArgs::xb); otherwise channel-first fp32 without an input activation.
+// ===================================================================================================
+template <bool XB>
+__global__ __launch_bounds__(G1_NTH, XB ? 3 : 2) void convs_bf16_kernel(ConvGemmArgs a, int HL, int XW, int tiles_per_unit, int n_tiles) {
+    constexpr int BN = 32, KG = 8;                      // one 32-row tile; k-groups (of 8 channels) per stage
+    constexpr int XPM = 6;                              // (k-group, position) pairs per thread and stage (host checks)
+    constexpr int WPM = 7;                              // 16-byte weight elements per thread: 2 blocks x ntaps <= 7 x 4 x 32 / 256
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw_all[];
+    float *Pm = reinterpret_cast<float *>(smem_raw_all);                   // [4][BN]
+    uint4 *Xs = reinterpret_cast<uint4 *>(smem_raw_all + 16 * BN);         // [KG][XW]
+    uint4 *Ws = Xs + KG * XW;                                              // [2][ntaps][4][BN]
+
+    int nwg = gridDim.x, orig = blockIdx.x;
+    int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+    int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    int nt = id % n_tiles;
+    int pt = id / n_tiles;
+    int unit = pt / tiles_per_unit;
+    int m0 = (pt - unit * tiles_per_unit) * G1_BM;
+    int n0 = nt * BN;
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int ncb = (a.Cin + 31) / 32;                  // channel blocks of the packed weight tensor
+    const int ngr = (a.Cin + 7) >> 3;                   // k-groups of the input
+    const int nst = (ncb + 1) / 2;
+    const int wtot = 2 * a.ntaps * 4 * BN;              // weight elements per stage
+
+    fill_param_table<BN, false>(a, Pm, n0, tid, G1_NTH);
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+
+    // ---- X pairs: p = tid + 256 j -> k-group p / XW, tile position p % XW
+    int xg[XPM];                                        // k-group within the stage, or -1
+    long xoff[XPM];                                     // element offset at stage 0 (position clamped)
+    unsigned xokm = 0;                                  // bit j: the position is inside [0, Lin)
+#pragma unroll
+    for (int j = 0; j < XPM; j++) {
+        const int p = tid + G1_NTH * j;
+        const int kg = p / XW, t = p - kg * XW;
+        const bool ex = kg < KG;
+        int pos = m0 - HL + t;
+        if (pos >= 0 && pos < a.Lin) xokm |= 1u << j;
+        pos = pos < 0 ? 0 : (pos >= a.Lin ? a.Lin - 1 : pos);
+        xg[j] = ex ? kg : -1;
+        xoff[j] = XB ? (long)unit * a.x_us + (long)(ex ? kg : 0) * a.x_cs + pos
+                     : (long)unit * a.x_us + (long)(ex ? kg : 0) * 8 * a.x_cs + pos;
+    }
+    const uint4 *xq = reinterpret_cast<const uint4 *>(a.xb);
+    const uint4 *wg = reinterpret_cast<const uint4 *>(a.wb);
+    uint4 xr[XPM], wr[WPM];
+    float xf[XB ? 1 : XPM][8];
+    auto fetch = [&](int st) {
+#pragma unroll
+        for (int j = 0; j < XPM; j++) {
+            const int g = st * KG + (xg[j] < 0 ? 0 : xg[j]);
+            if constexpr (XB) {
+                xr[j] = xq[g < ngr ? xoff[j] + (long)st * KG * a.x_cs : xoff[j] - (long)(xg[j] < 0 ? 0 : xg[j]) * a.x_cs];
+            } else {
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    const int ch = g * 8 + c;
+                    xf[j][c] = a.x[ch < a.Cin ? xoff[j] + ((long)st * KG * 8 + c) * a.x_cs
+                                              : xoff[j] - (long)(xg[j] < 0 ? 0 : xg[j]) * 8 * a.x_cs];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < WPM; j++) {
+            const int q = tid + G1_NTH * j;
+            const int slab = q / (4 * BN), rem = q - slab * (4 * BN);     // slab = (block of the stage, tap)
+            const int cbi = slab / a.ntaps, tap = slab - cbi * a.ntaps;
+            const int cb = 2 * st + cbi;
+            const bool ok = q < wtot && cb < ncb;
+            wr[j] = wg[ok ? ((long)(tap * ncb + cb) * 4 + rem / BN) * a.NP + n0 + rem % BN : 0];
+        }
+    };
+    auto commit = [&](int st) {
+#pragma unroll
+        for (int j = 0; j < XPM; j++) {
+            if (xg[j] < 0) continue;
+            const bool pok = (xokm >> j) & 1;
+            uint4 v;
+            if constexpr (XB) {
+                v = xr[j];
+                if (!pok || st * KG + xg[j] >= ngr) v = make_uint4(0, 0, 0, 0);
+            } else {
+                g1_bf16x8 o;
+#pragma unroll
+                for (int c = 0; c < 8; c++) o[c] = (__bf16)((pok && (st * KG + xg[j]) * 8 + c < a.Cin) ? xf[j][c] : 0.0f);
+                v = __builtin_bit_cast(uint4, o);
+            }
+            Xs[tid + G1_NTH * j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < WPM; j++) {
+            const int q = tid + G1_NTH * j;
+            if (q >= wtot) continue;
+            const int cbi = (q / (4 * BN)) / a.ntaps;
+            uint4 v = wr[j];
+            if (2 * st + cbi >= ncb) v = make_uint4(0, 0, 0, 0);
+            Ws[q] = v;
+        }
+    };
+
+    fetch(0);
+    for (int st = 0; st < nst; st++) {
+        __syncthreads();                                 // the previous stage's readers are past
+        commit(st);
+        fetch(st + 1 < nst ? st + 1 : st);               // unconditional; in flight during this stage's MFMAs
+        __syncthreads();
+        const g1_bf16x8 *wsb = reinterpret_cast<const g1_bf16x8 *>(Ws) + l31;
+        const g1_bf16x8 *xsb = reinterpret_cast<const g1_bf16x8 *>(Xs) + wave * 32 + l31 + HL + a.shift0;
+        for (int cbi = 0; cbi < 2; cbi++)
+            for (int tap = 0; tap < a.ntaps; tap++) {
+                const g1_bf16x8 *ws = wsb + (cbi * a.ntaps + tap) * 4 * BN;
+                const g1_bf16x8 *xs = xsb + cbi * 4 * XW + tap * a.shift_step;
+                g1_bf16x8 b0 = xs[h * XW], b1 = xs[(2 + h) * XW];
+                g1_bf16x8 a0 = ws[h * BN], a1 = ws[(2 + h) * BN];
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc, 0, 0, 0);
+            }
+    }
+
+    float *yu = a.y ? a.y + (long)unit * a.y_us : nullptr;
+    const float *ru0 = launder_after(a.res, acc[15]);
+    const float *ru = ru0 ? ru0 + (long)unit * a.y_us : nullptr;
+    float *y2u0 = launder_after(a.y2, acc[15]);
+    float *y2u = y2u0 ? y2u0 + (long)unit * a.y_us : nullptr;
+    unsigned short *ybu0 = launder_after(a.yb, acc[15]);
+    unsigned short *ybu = ybu0 ? ybu0 + (((long)unit * a.y_us) << 3) : nullptr;
+    const int m = m0 + wave * 32 + l31;
+    conv_epilogue_tile<BN>(a, acc, Pm, n0, 4 * h, m, yu, ru, y2u, ybu);
+}
+
+static bool convs_bf16_supported(const ConvGemmArgs &a) {
+    if (!(a.wb && !a.wb2 && !a.w2 && a.ntaps >= 5 && a.ntaps <= 7 && a.S >= 1 && !a.in_elu && a.s2d <= 1 && !a.sn_a &&
+          !((uintptr_t)a.wb & 15) && !(a.NP % 32) && a.NP >= a.N && a.Lin >= 1 && a.act != ACT_ELU && a.act != ACT_GELU_TANH &&
+          (a.y || a.yb) && (!a.y2 || (a.psn_a && a.psn_ib && !a.yb))))
+        return false;
+    if (a.xb && ((a.Cin & 7) || ((uintptr_t)a.xb & 15))) return false;
+    if (a.yb && (((a.N / a.S) & 7) || (a.N % a.S) || ((uintptr_t)a.yb & 15))) return false;
+    int HL, XW;
+    detail::conv_gemm_geometry(a, HL, XW, G1_BM);
+    return 8 * XW <= G1_NTH * 6;
+}
+
+bool convs_bf16_selected(const ConvGemmArgs &a) {
+    const char *e = getenv("HIPVOC_CONVS_WGS");
+    const int max_wgs = e ? atoi(e) : 384;              // (b1's conv7 on one utterance, 480 workgroups: 22 % slower here)
+    if (max_wgs <= 0 || !convs_bf16_supported(a)) return false;
+    const long tiles_m = (long)((a.M + 255) / 256) * a.units;
+    return tiles_m * (a.NP / (32 * detail::conv_gemm_launch_tn(a))) <= max_wgs;
+}
+
+const char *convs_bf16_kernel_name(const ConvGemmArgs &a) {
+    return a.xb ? "convs_bf16_kernel<true>" : "convs_bf16_kernel<false>";
+}
+
+template <bool XB>
+static hipError_t convs_bf16_launch_one(const ConvGemmArgs &a, int HL, int XW, int tiles_per_unit, int n_tiles, long grid, size_t lds, hipStream_t s) {
+    static bool done[64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64 && !done[dev]) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(convs_bf16_kernel<XB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        done[dev] = true;
+    }
+    hipLaunchKernelGGL((convs_bf16_kernel<XB>), dim3((unsigned)grid), dim3(G1_NTH), lds, s, a, HL, XW, tiles_per_unit, n_tiles);
+    return hipGetLastError();
+}
+
+hipError_t launch_convs_bf16(const ConvGemmArgs &a, hipStream_t s) {
+    if (a.M <= 0 || a.units <= 0) return hipSuccess;
+    if (!convs_bf16_supported(a)) return hipErrorInvalidValue;
+    int HL, XW;
+    detail::conv_gemm_geometry(a, HL, XW, G1_BM);
+    const int tiles_per_unit = (a.M + G1_BM - 1) / G1_BM;
+    const int n_tiles = a.NP / 32;
+    const long grid = (long)tiles_per_unit * a.units * n_tiles;
+    if (grid > 0x7fffffffL) return hipErrorInvalidValue;
+    const size_t lds = 16 * 32 + 16 * ((size_t)8 * XW + (size_t)2 * a.ntaps * 4 * 32);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    return a.xb ? convs_bf16_launch_one<true>(a, HL, XW, tiles_per_unit, n_tiles, grid, lds, s)
+                : convs_bf16_launch_one<false>(a, HL, XW, tiles_per_unit, n_tiles, grid, lds, s);
+}
+
 }  // namespace hipvoc

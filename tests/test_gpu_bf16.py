@@ -195,10 +195,13 @@ def test_bf16_gemm1_bitwise(pkg, synth, cfg_name, unit, frames, monkeypatch):
     outs = []
     for wgs in ("0", "1000000"):
         monkeypatch.setenv("HIPVOC_GEMM1_WGS", wgs)
+        monkeypatch.setenv("HIPVOC_CONVS_WGS", wgs)             # and conv7 (convs_bf16_kernel, packed and fp32 input)
         v = pkg.HipVocoder.load(path, device=0, unit_frames=unit, dtype=1)
         v.set_profile(True)
         outs.append(v.synthesize(codes))
-        used = any("gemm1_bf16_kernel" in k for k in v.last_profile())
-        assert used == (wgs != "0"), (wgs, sorted(v.last_profile()))
+        # (only the full-size model has packed conv7 inputs and an un-fused dec0 conv7 wide enough for both forms)
+        for name in ("gemm1_bf16_kernel", "convs_bf16_kernel<true>", "convs_bf16_kernel<false>")[: 3 if cfg_name == "FULL" else 1]:
+            used = any(name in k for k in v.last_profile())
+            assert used == (wgs != "0"), (wgs, name, sorted(v.last_profile()))
         del v
     assert outs[0].size and np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
