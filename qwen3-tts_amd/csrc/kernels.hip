@@ -969,20 +969,35 @@ __global__ __launch_bounds__(256) void dwconv_ln_reg_kernel(const float *x, floa
     long cs = (long)G * Lp, base = (long)u * Lp + t;
     float v[NPT];
     float sum = 0.0f;
+    // Every load is unconditional from a clamped address (a load under a per-lane condition makes hipcc branch around it
+    // and wait for it: 896 dependent round trips per thread, 145 us per launch), and the loads of EIGHT channels are
+    // issued before the first of them is used; what must not count is selected away afterwards.
+    constexpr int CG = 8;
+    static_assert(NPT % CG == 0, "channel groups");
 #pragma unroll
-    for (int j = 0; j < NPT; j++) {
-        int c = sl + 8 * j;
-        float acc = 0.0f;
-        if (c < C) {
-            acc = dw_b[c];
-            const float *xr = x + (long)c * cs + (long)u * Lp;
+    for (int jb = 0; jb < NPT; jb += CG) {
+        float xv[CG][K], wv[CG][K], bb[CG];
+#pragma unroll
+        for (int g = 0; g < CG; g++) {
+            const int c = sl + 8 * (jb + g), cc = c < C ? c : C - 1;
+            const float *xr = x + (long)cc * cs + (long)u * Lp;
 #pragma unroll
             for (int q = 0; q < K; q++) {
-                int sidx = tc - (K - 1 - q);
-                if (sidx >= 0) acc += dw_w[c * K + q] * xr[sidx];
+                const int sidx = tc - (K - 1 - q);
+                xv[g][q] = xr[sidx < 0 ? 0 : sidx];
+                wv[g][q] = dw_w[cc * K + q];
             }
+            bb[g] = dw_b[cc];
         }
-        v[j] = acc;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < CG; g++) {
+            float acc = bb[g];
+#pragma unroll
+            for (int q = 0; q < K; q++) acc = (tc - (K - 1 - q) >= 0) ? acc + wv[g][q] * xv[g][q] : acc;
+            v[jb + g] = (sl + 8 * (jb + g) < C) ? acc : 0.0f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int j = 0; j < NPT; j++) sum += v[j];
