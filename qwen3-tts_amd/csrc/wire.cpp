@@ -201,13 +201,17 @@ struct Wr {
     // Vec<u8> as rmp-serde writes it: array of minimal-width unsigned ints
     void bytes_as_ints(const uint8_t *b, size_t l) {
         array(l);
-        if (n + 2 * l <= cap) {                     // fast path: room for the worst case
-            uint8_t *o = out + n;
-            for (size_t k = 0; k < l; k++) { uint8_t v = b[k]; if (v >= 128) *o++ = 0xcc; *o++ = v; }
-            n = (size_t)(o - out);
-        } else {
-            for (size_t k = 0; k < l; k++) { if (b[k] >= 128) put(0xcc); put(b[k]); }
+        size_t hi_n = 0;                            // one byte each plus a 0xcc marker for values >= 128
+        for (size_t k = 0; k < l; k++) hi_n += b[k] >> 7;
+        if (!out || n + l + hi_n > cap) {           // sizing pass, or no room: count only (put() semantics)
+            n += l + hi_n;
+            return;
         }
+        // branch-free (the high bytes of PCM samples are coin flips for a branch predictor); an element writes only its
+        // own one or two bytes, so the exact-size buffer of the usual size-then-encode call pair is enough
+        uint8_t *o = out + n;
+        for (size_t k = 0; k < l; k++) { const uint8_t v = b[k]; const unsigned hi = v >> 7; o[0] = 0xcc; o[hi] = v; o += 1 + hi; }
+        n = (size_t)(o - out);
     }
 };
 

@@ -21,6 +21,7 @@
 #include <poll.h>
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -76,8 +77,8 @@ static void gpu_service(Gpu *g) {
             g->batches++; g->jobs += (long)take.size();
             if ((long)take.size() > g->max_batch) g->max_batch = (long)take.size();
         }
-        // one batched pass for everything that was waiting
         size_t B = take.size();
+        // one batched pass for everything that was waiting
         std::vector<int64_t> all;
         std::vector<int32_t> nf(B);
         std::vector<size_t> off(B + 1, 0), n_out(B, 0);
@@ -193,13 +194,21 @@ static std::vector<uint8_t> handle(const std::vector<uint8_t> &msg) {
         std::vector<Job> jobs(1);
         jobs[0].codes = c64.data();
         jobs[0].n_frames = (int)nt;
+        static const bool trace = getenv("HIPVOC_WORKER_TIMING") != nullptr;     // per-request host timing to stderr
+        auto t0 = std::chrono::steady_clock::now();
         run_jobs(jobs);
+        auto t1 = std::chrono::steady_clock::now();
         if (jobs[0].rc) return simple(0, "Init", jobs[0].err.c_str());
         std::vector<int16_t> &pcm = jobs[0].pcm;
         int16_t dummy = 0;
         const int16_t *pp = pcm.empty() ? &dummy : pcm.data();
         std::vector<uint8_t> b(hipvoc_wire_encode_vocode(pp, pcm.size(), nullptr, 0));
         hipvoc_wire_encode_vocode(pp, pcm.size(), b.data(), b.size());
+        if (trace) {
+            auto t2 = std::chrono::steady_clock::now();
+            fprintf(stderr, "vocode %d frames: queue+decode+pcm %.3f ms, encode %.3f ms (%zu bytes)\n", (int)nt,
+                    std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t1).count(), b.size());
+        }
         return b;
     }
     if (kind == HIPVOC_WIRE_VOCODE_BATCH) {

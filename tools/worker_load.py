@@ -68,6 +68,8 @@ def main():
     out = w.stdout.read()
     print(f"{dtype} devices={devices}: {P} clients x {R} requests x 10 s, {inflight} in flight each: {P*R*10/wall:.0f} audio-s/s through the worker "
           f"(slowest client {max(times):.2f} s)")
+    if P == 1 and inflight == 1:
+        print(f"  one client, one request at a time: {1e3 * max(times) / R:.2f} ms per 10 s utterance, request sent -> response (PCM16) fully read")
     print(out.strip()[-400:])
 
 
