@@ -33,6 +33,12 @@ FRAMES_PER_UTT = 125            # 10.0 s at 12.5 Hz
 AUDIO_S_PER_UTT = FRAMES_PER_UTT * 1920 / 24000.0
 PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md, dense bf16
+MODE_TEXT = {
+    "f32": "fp32",
+    "bf16": "bf16 conv-GEMM mode (fp32 accumulate; parity_vs_oracle is against the fp32 oracle)",
+    "bf16x3": "bf16x3 split-operand mode (operands as hi + mid bf16 planes, three bf16 MFMAs per product, fp32 accumulate; "
+              "held to the fp32 gates: parity_vs_oracle is against the fp32 oracle)",
+}
 
 
 def pmc_traffic(kernel, units_per_pass):
@@ -59,9 +65,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--utterances", type=int, default=UTTERANCES_PER_GPU)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
-                    help="f32 (default; the reference's precision and the headline number) or the bf16 conv-GEMM mode "
-                         "(BASELINE configs[4]; separately stated tolerance, never the default)")
+    ap.add_argument("--dtype", choices=["f32", "bf16", "bf16x3"], default="f32",
+                    help="f32 (default; the reference's precision and the headline number), the bf16 conv-GEMM mode "
+                         "(BASELINE configs[4]; separately stated tolerance) or the split-operand bf16x3 mode (fp32 gates, "
+                         "three bf16 MFMAs per product); never the default")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -83,7 +90,7 @@ def main():
     W = synth.make_weights(cfg, 0)
     wpath = os.path.join(tempfile.gettempdir(), f"hipvoc_bench_full_r{rank}.safetensors")
     synth.save_safetensors(wpath, W, cfg.metadata())
-    voc = pkg.HipVocoder.load(wpath, device=local_rank, unit_frames=64, dtype=1 if args.dtype == "bf16" else 0)
+    voc = pkg.HipVocoder.load(wpath, device=local_rank, unit_frames=64, dtype={"f32": 0, "bf16": 1, "bf16x3": 2}[args.dtype])
     os.remove(wpath)
 
     # --- synthetic workload: utterance u of rank r uses seed 1000 + r*U + u
@@ -158,7 +165,8 @@ def main():
         kd = kernels[dom]
         achieved = kd["flops"] / (kd["ms"] * 1e-3) / 1e12
         traffic, traffic_src = pmc_traffic(dom, G)
-        peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
+        # bf16x3: three bf16 MFMAs per algorithmic product, so the roof of the ALGORITHMIC rate is a third of the bf16 peak
+        peak = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "bf16x3": round(PEAK_BF16_MFMA_TFLOPS / 3, 1)}[args.dtype]
         roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 3), "peak": peak,
                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                     "traffic_source": traffic_src,
@@ -226,7 +234,7 @@ def main():
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"configs[2]: batched decode of {U} synthetic 10 s code sequences per GPU "
                                    f"(125 frames x 16 codebooks -> 2 reference units of 64 frames each), "
-                                   f"{'fp32' if args.dtype == 'f32' else 'bf16 conv-GEMM mode (fp32 accumulate; parity_vs_oracle is against the fp32 oracle)'}, "
+                                   f"{MODE_TEXT[args.dtype]}, "
                                    f"seeded random-init weights of the Qwen3-TTS 12 Hz decoder (114 M params)",
                        "utterances_per_gpu": U, "units_per_gpu": n_units, "unit_frames": T,
                        "units_per_pass": voc.group_units},

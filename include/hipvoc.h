@@ -36,6 +36,11 @@ extern "C" {
                                    (RNE), fp32 accumulate; RVQ, norms, attention, SnakeBeta, residuals and the final
                                    C->1 conv stay fp32.  Tolerance: see DESIGN.md / tests (not the fp32 gates). */
 
+#define HIPVOC_DTYPE_BF16X3 2   /* split-operand mode: every conv-GEMM operand is carried as two bf16 planes (hi + mid, 16
+                                   mantissa bits) and every product is three bf16 MFMAs with fp32 accumulate; everything
+                                   else as in the fp32 mode.  Meets the fp32 mode's waveform gates (max-abs 1e-3, SNR 60 dB
+                                   vs the fp32 CPU path; measured margin in DESIGN.md section 7b), not bit-equal to it. */
+
 #define HIPVOC_SAMPLES_PER_TOKEN 1920   /* src/worker/vocoder.rs:6, src/protocol.rs:122 */
 
 /* Number of visible HIP devices (0 if none / runtime unavailable). */

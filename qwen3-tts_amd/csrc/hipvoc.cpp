@@ -49,6 +49,7 @@ struct Gemm {
     float *w = nullptr;      // device [ntaps][CinP][NP] (fp32 mode)
     unsigned short *wb = nullptr;    // bf16 mode: [ntaps][CinP/32][4][NP][8] bf16 (kernels_bf16.hip)
     unsigned short *wb2 = nullptr;   // bf16 mode, 1x1 conv of a fusable residual unit: accumulator-order packing
+    unsigned short *wbm = nullptr, *wb2m = nullptr;   // bf16x3 mode: the mid planes bf16(w - hi) of wb / wb2
     float *bias = nullptr;   // device [N/S] or null
     int Cin = 0, N = 0, NP = 0, TN = 0, ntaps = 1, shift0 = 0, step = 0, S = 1;
     int pm = 0;              // transposed conv: rows are phase-major (n = phase * Cout + channel), see ConvGemmArgs::pm
@@ -107,6 +108,7 @@ struct Ctx {
     bool trim_right = false;   // trans-conv trim policy (metadata transconv_trim_right_only=1): keep L*r samples instead of (L-1)*r
     bool is_encoder = false;   // handle made by hipvoc_enc_load (encoder.inc.cpp): the vocoder entry points refuse it
     bool bf16 = false;         // HIPVOC_DTYPE_BF16: conv-GEMM operands in bf16, fp32 accumulate, everything else fp32
+    bool split3 = false;       // HIPVOC_DTYPE_BF16X3: bf16 = true as well; operands as two bf16 planes, three MFMAs per product
     int dual_out = 1;          // un-fused residual units, SnakeBeta in the producer's epilogue: 0 never, 1 conv7 -> conv1 only
                                // (no extra write), 2 also x / snake(x) written side by side (HIPVOC_DUAL)
     hipStream_t stream = nullptr;
@@ -226,6 +228,12 @@ struct Loader {
         u += 0x7fffu + ((u >> 16) & 1u);
         return (unsigned short)(u >> 16);
     }
+    static float from_bf16(unsigned short b) {
+        uint32_t u = (uint32_t)b << 16;
+        float f;
+        memcpy(&f, &u, 4);
+        return f;
+    }
     unsigned short *upload_u16(const std::vector<unsigned short> &v) {
         if (!ok) return nullptr;
         void *p = nullptr;
@@ -255,6 +263,17 @@ struct Loader {
                 for (int n = 0; n < g.NP; n++) dst[(size_t)n * 8] = to_bf16(src[n]);
             }
         g.wb = upload_u16(q);
+        if (c->split3) {               // mid plane: what the first bf16 leaves over, in the same layout
+            std::vector<unsigned short> qm(q.size());
+            for (int tap = 0; tap < g.ntaps; tap++)
+                for (int ci = 0; ci < CinP; ci++) {
+                    const int cb = ci / 32, kq = (ci % 32) / 8, j = ci % 8;
+                    const float *src = &p[((size_t)tap * CinP + ci) * g.NP];
+                    const size_t base = ((((size_t)tap * ncb + cb) * 4 + kq) * g.NP) * 8 + j;
+                    for (int n = 0; n < g.NP; n++) qm[base + (size_t)n * 8] = to_bf16(src[n] - from_bf16(q[base + (size_t)n * 8]));
+                }
+            g.wbm = upload_u16(qm);
+        }
         // a square single-tap conv whose rows fit one tile may be the second product of a fused residual unit:
         // W2 tile o = [2*NP/32 k-steps][2 lane halves][32 rows][8], element (ks = 2i+g, h, row, j) =
         // w[out = 32o+row][in = 32i + 16g + (j&3) + 8(j>>2) + 4h]  -- the channel a lane half holds in
@@ -272,6 +291,20 @@ struct Loader {
                                 w2[((((size_t)o * 2 * tn + ks) * 2 + h) * 32 + row) * 8 + j] = to_bf16(p[(size_t)in * g.NP + out]);
                             }
             g.wb2 = upload_u16(w2);
+            if (c->split3) {
+                std::vector<unsigned short> w2m(w2.size());
+                for (int o = 0; o < tn; o++)
+                    for (int ks = 0; ks < 2 * tn; ks++)
+                        for (int h = 0; h < 2; h++)
+                            for (int row = 0; row < 32; row++)
+                                for (int j = 0; j < 8; j++) {
+                                    int in = 32 * (ks >> 1) + 16 * (ks & 1) + (j & 3) + 8 * (j >> 2) + 4 * h;
+                                    int out = 32 * o + row;
+                                    const size_t idx = ((((size_t)o * 2 * tn + ks) * 2 + h) * 32 + row) * 8 + j;
+                                    w2m[idx] = to_bf16(p[(size_t)in * g.NP + out] - from_bf16(w2[idx]));
+                                }
+                g.wb2m = upload_u16(w2m);
+            }
         }
     }
     float *vec(const std::string &name, int expect) {
@@ -594,7 +627,7 @@ struct PlanBuilder {
         ConvGemmArgs a{};
         a.in_elu = in_elu;
         a.s2d = s2d;
-        a.x = x; a.y = y; a.w = g.w; a.wb = g.wb; a.bias = g.bias; a.res = res; a.rscale = rscale; a.y2 = post ? y2 : nullptr;
+        a.x = x; a.y = y; a.w = g.w; a.wb = g.wb; a.wbm = g.wbm; a.bias = g.bias; a.res = res; a.rscale = rscale; a.y2 = post ? y2 : nullptr;
         a.xb = xb; a.yb = yb;
         a.psn_a = post ? post->ea : nullptr; a.psn_ib = post ? post->ib : nullptr;
         a.sn_a = sn ? sn->ea : nullptr; a.sn_ib = sn ? sn->ib : nullptr;
@@ -627,7 +660,7 @@ struct PlanBuilder {
         a.x = x; a.y = y; a.w = c1.w; a.wb = c1.wb; a.bias = c1.bias; a.res = x; a.sn_a = s1.ea; a.sn_ib = s1.ib;
         a.xb = xb; a.yb = yb;
         if (xb) { a.sn_a = nullptr; a.sn_ib = nullptr; }      // the producer of xb already applied s1
-        a.w2 = c2.w; a.wb2 = c2.wb2; a.bias2 = c2.bias; a.sn2_a = s2.ea; a.sn2_ib = s2.ib;
+        a.w2 = c2.w; a.wb2 = c2.wb2; a.wbm = c1.wbm; a.wb2m = c2.wb2m; a.bias2 = c2.bias; a.sn2_a = s2.ea; a.sn2_ib = s2.ib;
         a.Cin = c1.Cin; a.N = c1.N; a.NP = c1.NP; a.TN = c1.TN;
         a.ntaps = c1.ntaps; a.shift0 = c1.shift0; a.shift_step = c1.step; a.S = 1; a.act = ACT_NONE;
         a.units = G; a.M = L; a.Lin = L; a.x_us = Lp; a.y_us = Lp; a.x_cs = (long)G * Lp; a.y_cs = (long)G * Lp;
@@ -760,7 +793,7 @@ static Plan *get_plan(Ctx *c, int G, int T, bool debug = false) {
     // bf16 mode: every tensor of the decoder stack that is only consumed as a GEMM operand is
     // exchanged as packed bf16 with the consumer's SnakeBeta applied by its producer (ConvGemmArgs::xb / yb); the
     // residual stream stays fp32.  Needs every channel count of the stack to be a multiple of 8.
-    bool packed = c->bf16 && c->packed && !c->blocks.empty() && c->dec_dim % 8 == 0;
+    bool packed = c->bf16 && !c->split3 && c->packed && !c->blocks.empty() && c->dec_dim % 8 == 0;
     for (size_t i = 0; packed && i < c->blocks.size(); i++) packed = (c->blocks[i].tc.N / c->rates[i]) % 8 == 0;
     if (packed) {
         unsigned short *pk[2] = {reinterpret_cast<unsigned short *>(b.buf(B_PK0, big / 2 + 64)),
@@ -1047,7 +1080,8 @@ void *hipvoc_load(const char *weights_path, int device_id, int dtype, int unit_f
         return nullptr;
     };
     if (!weights_path) return fail("weights_path is NULL");
-    if (dtype != HIPVOC_DTYPE_F32 && dtype != HIPVOC_DTYPE_BF16) return fail("dtype must be HIPVOC_DTYPE_F32 or HIPVOC_DTYPE_BF16");
+    if (dtype != HIPVOC_DTYPE_F32 && dtype != HIPVOC_DTYPE_BF16 && dtype != HIPVOC_DTYPE_BF16X3)
+        return fail("dtype must be HIPVOC_DTYPE_F32, HIPVOC_DTYPE_BF16 or HIPVOC_DTYPE_BF16X3");
     if (unit_frames < 1 || unit_frames > 4096) return fail("unit_frames out of range");
     int ndev = hipvoc_device_count();
     if (ndev <= 0) return fail("no HIP device available (libhipvoc has no CPU fallback)");
@@ -1056,7 +1090,8 @@ void *hipvoc_load(const char *weights_path, int device_id, int dtype, int unit_f
     std::unique_ptr<Ctx> c(new Ctx);
     c->device = device_id;
     c->unit_frames = unit_frames;
-    c->bf16 = dtype == HIPVOC_DTYPE_BF16;
+    c->bf16 = dtype == HIPVOC_DTYPE_BF16 || dtype == HIPVOC_DTYPE_BF16X3;
+    c->split3 = dtype == HIPVOC_DTYPE_BF16X3;
     if (const char *g = getenv("HIPVOC_GROUP")) c->group = std::max(1, std::min(128, atoi(g)));
     if (const char *pf = getenv("HIPVOC_PROFILE")) c->profile = atoi(pf) != 0;
     if (const char *fz = getenv("HIPVOC_FUSE")) c->fuse_res = atoi(fz) != 0;

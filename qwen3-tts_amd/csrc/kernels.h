@@ -40,6 +40,10 @@ struct ConvGemmArgs {
     // [2*NP/32 k-steps][2][32][8] bf16 in the k order of the accumulator registers (hipvoc.cpp)
     const unsigned short *wb;
     const unsigned short *wb2;
+    // split-operand mode (HIPVOC_DTYPE_BF16X3): the "mid" planes bf16(w - hi) of wb / wb2, same layouts; non-null wbm
+    // selects conv_gemm_bf16x3_kernel (three MFMAs per product: hi*hi + hi*mid + mid*hi), fp32 exchange only
+    const unsigned short *wbm;
+    const unsigned short *wb2m;
     // bf16 mode, packed activations (optional): tensors that are only ever consumed as GEMM operands are exchanged
     // as bf16 in channel-group-major form -- 16-byte element (c/8, u, t) at index (c/8)*cs + u*us + t, i.e. the
     // strides of the fp32 layout counted in 16-byte elements -- with the consumer's SnakeBeta already applied by

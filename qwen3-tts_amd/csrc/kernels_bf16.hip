@@ -41,9 +41,12 @@ __device__ __forceinline__ bf16x8 pack8(const f32x8 &v) {
 
 // XB: the input is a packed bf16 tensor (ConvGemmArgs::xb, activation already applied by its producer): staging a
 // (k-group, position) pair is ONE 16-byte load and one 16-byte LDS store -- no gather, no SnakeBeta, no conversion.
-template <int TN, bool FUSE, bool XB>
-__global__ __launch_bounds__(NTHB, (TN > 4) ? 2 : 4) void conv_gemm_bf16_kernel(ConvGemmArgs a, int HL, int XW,
-                                                                                 int tiles_per_unit, int n_tiles) {
+// X3 ("bf16x3", HIPVOC_DTYPE_BF16X3): every operand is split into two bf16 planes, v = hi + mid with hi = bf16(v) and
+// mid = bf16(v - hi) (16 mantissa bits together), and a product is three MFMAs: hi*hi + hi*mid + mid*hi (the dropped
+// mid*mid term is 2^-16 of the product).  fp32-grade results at a third of the bf16 MFMA rate -- still several
+// times the fp32 MFMA rate.  Weights are split once at load (ConvGemmArgs::wbm / wb2m), activations at commit.
+template <int TN, bool FUSE, bool XB, bool X3>
+__device__ __forceinline__ void conv_gemm_bf16_body(const ConvGemmArgs &a, int HL, int XW, int tiles_per_unit, int n_tiles) {
     constexpr int BN = TN * 32;
     constexpr int WF = 4 * BN;                        // 16-byte elements per W tile [4 k-groups][BN rows]
     constexpr int WPT = (WF + NTHB - 1) / NTHB;       // per thread: 1 (TN <= 4) or 2 (TN = 6)
@@ -53,8 +56,10 @@ __global__ __launch_bounds__(NTHB, (TN > 4) ? 2 : 4) void conv_gemm_bf16_kernel(
     float *Pm = reinterpret_cast<float *>(smem_all);
     unsigned char *smem_raw = smem_all + PMF * sizeof(float);
     bf16x8 *Xs = reinterpret_cast<bf16x8 *>(smem_raw);          // [2][4][XW]
-    bf16x8 *Ws = Xs + 2 * 4 * XW;                                // [2][4][BN]
-    float *Sn = reinterpret_cast<float *>(Ws + 2 * WF);          // [2][CinP]: exp(alpha) | 1/(exp(beta)+1e-9)
+    bf16x8 *Xm = Xs + 2 * 4 * XW;                                // X3: the mid plane, same shape
+    bf16x8 *Ws = Xs + (X3 ? 4 : 2) * 4 * XW;                     // [2][4][BN]
+    bf16x8 *Wm = Ws + 2 * WF;                                    // X3: the mid plane
+    float *Sn = reinterpret_cast<float *>(Ws + (X3 ? 4 : 2) * WF);   // [2][CinP]: exp(alpha) | 1/(exp(beta)+1e-9)
 
     int nwg = gridDim.x, orig = blockIdx.x;
     int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
@@ -90,7 +95,8 @@ __global__ __launch_bounds__(NTHB, (TN > 4) ? 2 : 4) void conv_gemm_bf16_kernel(
 
     // ---- W staging: the packed tensor is [tap][cb][4 k-groups][NP rows] of 16-byte elements
     const uint4 *wg = reinterpret_cast<const uint4 *>(a.wb);
-    uint4 w0 = make_uint4(0, 0, 0, 0), w1 = w0;
+    const uint4 *wgm = reinterpret_cast<const uint4 *>(a.wbm);
+    uint4 w0 = make_uint4(0, 0, 0, 0), w1 = w0, wm0 = w0, wm1 = w0;
     const int wq0 = tid / BN, wr0 = tid - wq0 * BN;
     const int wq1 = (tid + NTHB) / BN, wr1 = tid + NTHB - wq1 * BN;
 #define W_LOAD(stage_)                                                                          \
@@ -99,12 +105,22 @@ __global__ __launch_bounds__(NTHB, (TN > 4) ? 2 : 4) void conv_gemm_bf16_kernel(
         const uint4 *wp_ = wg + ((long)(tap_ * ncb + cb_) * 4) * a.NP + n0;                     \
         if (WF >= NTHB || tid < WF) w0 = wp_[(long)wq0 * a.NP + wr0];                           \
         if constexpr (WPT > 1) if (tid + NTHB < WF) w1 = wp_[(long)wq1 * a.NP + wr1];           \
+        if constexpr (X3) {                                                                     \
+            const uint4 *wpm_ = wgm + ((long)(tap_ * ncb + cb_) * 4) * a.NP + n0;               \
+            if (WF >= NTHB || tid < WF) wm0 = wpm_[(long)wq0 * a.NP + wr0];                     \
+            if constexpr (WPT > 1) if (tid + NTHB < WF) wm1 = wpm_[(long)wq1 * a.NP + wr1];     \
+        }                                                                                       \
     }
 #define W_STORE(buf_)                                                                           \
     {                                                                                           \
         uint4 *ws_ = reinterpret_cast<uint4 *>(Ws) + (buf_)*WF + tid;                           \
         if (WF >= NTHB || tid < WF) *ws_ = w0;                                                  \
         if constexpr (WPT > 1) if (tid + NTHB < WF) ws_[NTHB] = w1;                             \
+        if constexpr (X3) {                                                                     \
+            uint4 *wsm_ = reinterpret_cast<uint4 *>(Wm) + (buf_)*WF + tid;                      \
+            if (WF >= NTHB || tid < WF) *wsm_ = wm0;                                            \
+            if constexpr (WPT > 1) if (tid + NTHB < WF) wsm_[NTHB] = wm1;                       \
+        }                                                                                       \
     }
 
     // ---- X staging: (k-group, position) pairs p = tid + 512*round, k-group = p / XW, position = p % XW; the LDS
@@ -170,7 +186,14 @@ __global__ __launch_bounds__(NTHB, (TN > 4) ? 2 : 4) void conv_gemm_bf16_kernel(
             f32x2 p3 = snake_beta2(mk2(v[6], v[7]), mk2(a1.z, a1.w), mk2(b1.z, b1.w));
             v[0] = p0.x; v[1] = p0.y; v[2] = p1.x; v[3] = p1.y; v[4] = p2.x; v[5] = p2.y; v[6] = p3.x; v[7] = p3.y;
         }
-        Xs[buf * 4 * XW + tid + round * NTHB] = pack8(v);
+        const bf16x8 hi = pack8(v);
+        Xs[buf * 4 * XW + tid + round * NTHB] = hi;
+        if constexpr (X3) {
+            f32x8 r;
+#pragma unroll
+            for (int j = 0; j < 8; j++) r[j] = v[j] - (float)hi[j];
+            Xm[buf * 4 * XW + tid + round * NTHB] = pack8(r);
+        }
     };
     // packed input: element (k-group cb*4+kq, unit, pos) of a.xb; the descriptor ends after the last real group
     uint4 qa = make_uint4(0, 0, 0, 0), qb = qa, qc = qa;
@@ -232,6 +255,17 @@ __global__ __launch_bounds__(NTHB, (TN > 4) ? 2 : 4) void conv_gemm_bf16_kernel(
                     bf16x8 av[TN];
 #pragma unroll
                     for (int i = 0; i < TN; i++) av[i] = wsb[kq * BN + i * 32];
+                    if constexpr (X3) {
+                        const bf16x8 bm = (xsb + (Xm - Xs))[kq * XW];
+                        bf16x8 am[TN];
+#pragma unroll
+                        for (int i = 0; i < TN; i++) am[i] = (wsb + (Wm - Ws))[kq * BN + i * 32];
+#pragma unroll
+                        for (int i = 0; i < TN; i++) {      // small terms first
+                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bv, acc[i], 0, 0, 0);
+                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bm, acc[i], 0, 0, 0);
+                        }
+                    }
 #pragma unroll
                     for (int i = 0; i < TN; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv, acc[i], 0, 0, 0);
                 }
@@ -262,7 +296,13 @@ __global__ __launch_bounds__(NTHB, (TN > 4) ? 2 : 4) void conv_gemm_bf16_kernel(
         const uint4 *w2g = reinterpret_cast<const uint4 *>(launder_after(a.wb2, acc[0][15]));
         if (tid < W2N) w0 = w2g[tid];
         if constexpr (W2N > NTHB) if (tid + NTHB < W2N) w1 = w2g[tid + NTHB];
+        if constexpr (X3) {
+            const uint4 *w2gm = reinterpret_cast<const uint4 *>(launder_after(a.wb2m, acc[0][15]));
+            if (tid < W2N) wm0 = w2gm[tid];
+            if constexpr (W2N > NTHB) if (tid + NTHB < W2N) wm1 = w2gm[tid + NTHB];
+        }
         bf16x8 hb[TN][2];
+        bf16x8 hm[X3 ? TN : 1][2];
 #pragma unroll
         for (int i = 0; i < TN; i++) {
 #pragma unroll
@@ -282,15 +322,23 @@ __global__ __launch_bounds__(NTHB, (TN > 4) ? 2 : 4) void conv_gemm_bf16_kernel(
 #pragma unroll
             for (int g = 0; g < 2; g++)
 #pragma unroll
-                for (int j = 0; j < 8; j++) hb[i][g][j] = (__bf16)acc[i][8 * g + j];
+                for (int j = 0; j < 8; j++) {
+                    hb[i][g][j] = (__bf16)acc[i][8 * g + j];
+                    if constexpr (X3) hm[i][g][j] = (__bf16)(acc[i][8 * g + j] - (float)hb[i][g][j]);
+                }
         }
         float *yu = a.y ? a.y + (long)unit * a.y_us : nullptr;
         unsigned short *ybu = a.yb ? a.yb + (((long)unit * a.y_us) << 3) : nullptr;
         const int m = m0 + wave * 32 + l31;
         uint4 *w2s = reinterpret_cast<uint4 *>(smem_raw);
+        uint4 *w2sm = w2s + 2 * W2N;              // X3: the mid planes of the two tile buffers
         __syncthreads();                          // every wave is done with the main loop's tiles
         if (tid < W2N) w2s[tid] = w0;
         if constexpr (W2N > NTHB) if (tid + NTHB < W2N) w2s[tid + NTHB] = w1;
+        if constexpr (X3) {
+            if (tid < W2N) w2sm[tid] = wm0;
+            if constexpr (W2N > NTHB) if (tid + NTHB < W2N) w2sm[tid + NTHB] = wm1;
+        }
         float dep2 = acc[TN - 1][15];
 #pragma unroll
         for (int o = 0; o < TN; o++) {
@@ -298,6 +346,11 @@ __global__ __launch_bounds__(NTHB, (TN > 4) ? 2 : 4) void conv_gemm_bf16_kernel(
                 const uint4 *wq_ = reinterpret_cast<const uint4 *>(launder_after(a.wb2, dep2)) + (o + 1) * W2N;
                 if (tid < W2N) w0 = wq_[tid];
                 if constexpr (W2N > NTHB) if (tid + NTHB < W2N) w1 = wq_[tid + NTHB];
+                if constexpr (X3) {
+                    const uint4 *wqm_ = reinterpret_cast<const uint4 *>(launder_after(a.wb2m, dep2)) + (o + 1) * W2N;
+                    if (tid < W2N) wm0 = wqm_[tid];
+                    if constexpr (W2N > NTHB) if (tid + NTHB < W2N) wm1 = wqm_[tid + NTHB];
+                }
             }
             __syncthreads();
             float resv[16];   // this tile's residual, in flight during its product
@@ -316,12 +369,22 @@ __global__ __launch_bounds__(NTHB, (TN > 4) ? 2 : 4) void conv_gemm_bf16_kernel(
 #pragma unroll
             for (int i = 0; i < TN; i++)
 #pragma unroll
-                for (int g = 0; g < 2; g++)
+                for (int g = 0; g < 2; g++) {
+                    if constexpr (X3) {
+                        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16((ws + 2 * W2N)[(i * 2 + g) * 64], hb[i][g], acc2, 0, 0, 0);
+                        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ws[(i * 2 + g) * 64], hm[i][g], acc2, 0, 0, 0);
+                    }
                     acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ws[(i * 2 + g) * 64], hb[i][g], acc2, 0, 0, 0);
+                }
             if (o + 1 < TN) {
                 uint4 *wd_ = w2s + ((o + 1) & 1) * W2N;
                 if (tid < W2N) wd_[tid] = w0;
                 if constexpr (W2N > NTHB) if (tid + NTHB < W2N) wd_[tid + NTHB] = w1;
+                if constexpr (X3) {
+                    uint4 *wdm_ = w2sm + ((o + 1) & 1) * W2N;
+                    if (tid < W2N) wdm_[tid] = wm0;
+                    if constexpr (W2N > NTHB) if (tid + NTHB < W2N) wdm_[tid + NTHB] = wm1;
+                }
             }
             dep2 = acc2[15];
             fused_epilogue_tile<BN>(a, acc2, resv, Pm, o * 32 + 4 * h, m, yu, ybu);
@@ -342,14 +405,27 @@ __global__ __launch_bounds__(NTHB, (TN > 4) ? 2 : 4) void conv_gemm_bf16_kernel(
     for (int i = 0; i < TN; i++) conv_epilogue_tile<BN>(a, acc[i], Pm, n0, i * 32 + 4 * h, m, yu, ru, y2u, ybu);
 }
 
+template <int TN, bool FUSE, bool XB>
+__global__ __launch_bounds__(NTHB, (TN > 4) ? 2 : 4) void conv_gemm_bf16_kernel(ConvGemmArgs a, int HL, int XW,
+                                                                                 int tiles_per_unit, int n_tiles) {
+    conv_gemm_bf16_body<TN, FUSE, XB, false>(a, HL, XW, tiles_per_unit, n_tiles);
+}
+// the split-operand mode (fp32 exchange between kernels; one 8-wave workgroup per CU)
+template <int TN, bool FUSE>
+__global__ __launch_bounds__(NTHB, 2) void conv_gemm_bf16x3_kernel(ConvGemmArgs a, int HL, int XW, int tiles_per_unit,
+                                                                   int n_tiles) {
+    conv_gemm_bf16_body<TN, FUSE, false, true>(a, HL, XW, tiles_per_unit, n_tiles);
+}
+
 // ---------------------------------------------------------------------------------------------------
 size_t conv_gemm_bf16_lds_bytes(const ConvGemmArgs &a) {
     int HL, XW;
     detail::conv_gemm_geometry(a, HL, XW);
     const int tn = detail::conv_gemm_launch_tn(a);
     const int CinP = (a.Cin + BKB - 1) / BKB * BKB;
-    size_t b = 16 * (2 * 4 * (size_t)XW + 2 * 4 * (size_t)32 * tn) + (a.sn_a ? 2 * sizeof(float) * CinP : 0);
-    if (a.wb2) b = b > 2 * 16 * (size_t)128 * tn ? b : 2 * 16 * (size_t)128 * tn;
+    const size_t planes = a.wbm ? 2 : 1;
+    size_t b = planes * 16 * (2 * 4 * (size_t)XW + 2 * 4 * (size_t)32 * tn) + (a.sn_a ? 2 * sizeof(float) * CinP : 0);
+    if (a.wb2) b = b > planes * 2 * 16 * (size_t)128 * tn ? b : planes * 2 * 16 * (size_t)128 * tn;
     b += sizeof(float) * (a.wb2 ? 6 : 4) * 32 * tn;     // per-row parameter table
     return b;
 }
@@ -361,6 +437,12 @@ const char *conv_gemm_bf16_kernel_name(const ConvGemmArgs &a) {
     int tn = detail::conv_gemm_launch_tn(a);
     int fuse = a.wb2 ? 1 : 0, xbf = a.xb ? 1 : 0;
     char *n = names[fuse][xbf][tn & 7];
+    if (a.wbm) {
+        static char n3[2][8][48];
+        char *m = n3[fuse][tn & 7];
+        if (!m[0]) snprintf(m, 48, "conv_gemm_bf16x3_kernel<%d,%s>", tn, fuse ? "true" : "false");
+        return m;
+    }
     if (!n[0]) snprintf(n, 56, "conv_gemm_bf16_kernel<%d,%s,%s>", tn, fuse ? "true" : "false", xbf ? "true" : "false");
     return n;
 }
@@ -379,6 +461,24 @@ static hipError_t launch_one_bf16(const ConvGemmArgs &a, int HL, int XW, int til
         done[dev] = true;
     }
     hipLaunchKernelGGL((conv_gemm_bf16_kernel<TN, FUSE, XB>), dim3((unsigned)grid), dim3(NTHB), lds, s, a, HL, XW,
+                       tiles_per_unit, n_tiles);
+    return hipGetLastError();
+}
+
+template <int TN, bool FUSE>
+static hipError_t launch_one_bf16x3(const ConvGemmArgs &a, int HL, int XW, int tiles_per_unit, int n_tiles, long grid,
+                                    size_t lds, hipStream_t s) {
+    static bool done[64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64 && !done[dev]) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_gemm_bf16x3_kernel<TN, FUSE>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        done[dev] = true;
+    }
+    hipLaunchKernelGGL((conv_gemm_bf16x3_kernel<TN, FUSE>), dim3((unsigned)grid), dim3(NTHB), lds, s, a, HL, XW,
                        tiles_per_unit, n_tiles);
     return hipGetLastError();
 }
@@ -422,6 +522,15 @@ hipError_t launch_conv_gemm_bf16(const ConvGemmArgs &a_in, hipStream_t s) {
         case 3: GOX(3, F_, X_);     \
         case 4: GOX(4, F_, X_);     \
         default: break;             \
+    }
+    if (a.wbm) {     // split-operand mode: fp32 exchange only
+        if (a.xb || a.yb || ((uintptr_t)a.wbm & 15) || (a.wb2 && (!a.wb2m || ((uintptr_t)a.wb2m & 15)))) return hipErrorInvalidValue;
+#define GO3(TN_, F_) return launch_one_bf16x3<TN_, F_>(a, HL, XW, tiles_per_unit, n_tiles, grid, lds, s)
+        if (a.wb2) {
+            switch (tn) { case 1: GO3(1, true); case 2: GO3(2, true); case 3: GO3(3, true); case 4: GO3(4, true); default: GO3(6, true); }
+        }
+        switch (tn) { case 1: GO3(1, false); case 2: GO3(2, false); case 3: GO3(3, false); default: GO3(4, false); }
+#undef GO3
     }
     if (a.wb2) {
         if (a.xb) { SW(true, true) GOX(6, true, true); }

@@ -604,7 +604,7 @@ __global__ __launch_bounds__(G1_NTH, 2) void gemm1_bf16_kernel(ConvGemmArgs a, i
 }
 
 static bool g1b_supported(const ConvGemmArgs &a) {
-    return a.wb && !a.wb2 && !a.w2 && !a.xb && !a.yb && a.y && a.ntaps == 1 && a.shift0 == 0 && a.S == 1 && !a.sn_a &&
+    return a.wb && !a.wbm && !a.wb2 && !a.w2 && !a.xb && !a.yb && a.y && a.ntaps == 1 && a.shift0 == 0 && a.S == 1 && !a.sn_a &&
            !a.in_elu && a.s2d <= 1 && !((uintptr_t)a.wb & 15) && a.TN >= 1 && a.TN <= 4 && !(a.NP % (32 * a.TN)) &&
            a.NP >= a.N && a.Lin >= 1 && a.act != ACT_ELU && a.act != ACT_GELU_TANH && (!a.y2 || (a.psn_a && a.psn_ib));
 }
@@ -807,7 +807,7 @@ __global__ __launch_bounds__(G1_NTH, XB ? 3 : 2) void convs_bf16_kernel(ConvGemm
 }
 
 static bool convs_bf16_supported(const ConvGemmArgs &a) {
-    if (!(a.wb && !a.wb2 && !a.w2 && a.ntaps >= 5 && a.ntaps <= 7 && a.S >= 1 && !a.in_elu && a.s2d <= 1 && !a.sn_a &&
+    if (!(a.wb && !a.wbm && !a.wb2 && !a.w2 && a.ntaps >= 5 && a.ntaps <= 7 && a.S >= 1 && !a.in_elu && a.s2d <= 1 && !a.sn_a &&
           !((uintptr_t)a.wb & 15) && !(a.NP % 32) && a.NP >= a.N && a.Lin >= 1 && a.act != ACT_ELU && a.act != ACT_GELU_TANH &&
           (a.y || a.yb) && (!a.y2 || (a.psn_a && a.psn_ib && !a.yb))))
         return false;

@@ -348,12 +348,12 @@ int main(int argc, char **argv) {
         if (a == "-b" || a == "--bind") bind_addr = next();
         else if (a == "-m" || a == "--model") model = next();
         else if (a == "--device" || a == "--devices") devices = next();
-        else if (a == "--dtype") { std::string d = next(); dtype = d == "bf16" ? HIPVOC_DTYPE_BF16 : HIPVOC_DTYPE_F32; }
+        else if (a == "--dtype") { std::string d = next(); dtype = d == "bf16" ? HIPVOC_DTYPE_BF16 : d == "bf16x3" ? HIPVOC_DTYPE_BF16X3 : HIPVOC_DTYPE_F32; }
         else if (a == "--unit-frames") unit = atoi(next());
         else if (a == "--max-batch") g_max_batch = atoi(next());
         else if (a == "--contexts") contexts = atoi(next());
         else if (a == "-r" || a == "--role") { std::string r = next(); if (r != "vocoder") { fprintf(stderr, "hipvoc-worker only serves role 'vocoder'\n"); return 2; } }
-        else { fprintf(stderr, "usage: hipvoc-worker -m <decoder.safetensors> [-b host:port] [--devices 0,1,..] [--dtype f32|bf16] [--unit-frames 64] [--max-batch 256] [--contexts 2]\n"); return 2; }
+        else { fprintf(stderr, "usage: hipvoc-worker -m <decoder.safetensors> [-b host:port] [--devices 0,1,..] [--dtype f32|bf16|bf16x3] [--unit-frames 64] [--max-batch 256] [--contexts 2]\n"); return 2; }
     }
     if (model.empty()) { fprintf(stderr, "hipvoc-worker: -m <weights.safetensors> is required\n"); return 2; }
     if (g_max_batch < 1) g_max_batch = 1;
@@ -393,7 +393,7 @@ int main(int argc, char **argv) {
     socklen_t sl = sizeof sa;
     getsockname(ls, (sockaddr *)&sa, &sl);
     printf("hipvoc-worker ready, listening on %s:%d (unit %d frames, %s, %zu device handle(s))\n", host.c_str(),
-           (int)ntohs(sa.sin_port), unit, dtype == HIPVOC_DTYPE_BF16 ? "bf16" : "f32", g_gpus.size());
+           (int)ntohs(sa.sin_port), unit, dtype == HIPVOC_DTYPE_BF16 ? "bf16" : dtype == HIPVOC_DTYPE_BF16X3 ? "bf16x3" : "f32", g_gpus.size());
     fflush(stdout);
     signal(SIGPIPE, SIG_IGN);
     signal(SIGTERM, on_term);

@@ -77,6 +77,9 @@ def load_library():
     return L
 
 
+DTYPE_F32, DTYPE_BF16, DTYPE_BF16X3 = 0, 1, 2      # include/hipvoc.h: HIPVOC_DTYPE_*
+
+
 class HipVocoder:
     """Vocoder: converts codec tokens -> audio waveform on one MI355X (vocoder.rs:14-18)."""
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-step device time of one bf16-mode pass (full model, HIPVOC_GROUP units)."""
+"""Per-step device time of one bf16-mode pass (full model, HIPVOC_GROUP units).  `bf16_steps.py x3`: the bf16x3 mode."""
 import os, sys, tempfile, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,7 +12,8 @@ cfg = synth.FULL
 path = os.path.join(tempfile.gettempdir(), "hipvoc_prof_full.safetensors")
 if not os.path.exists(path):
     synth.save_safetensors(path, synth.make_weights(cfg, 0), cfg.metadata())
-v = pkg.HipVocoder.load(path, unit_frames=64, dtype=1)
+X3 = len(sys.argv) > 1 and sys.argv[1] == "x3"
+v = pkg.HipVocoder.load(path, unit_frames=64, dtype=2 if X3 else 1)
 G = v.group_units
 codes = np.stack([synth.make_codes(64, 1000 + i, cfg) for i in range(G)])
 d_codes = torch.from_numpy(codes).cuda()
@@ -26,7 +27,7 @@ for _ in range(3):
     v.decode_units_device(d_codes.data_ptr(), G, d_out.data_ptr(), stride)
 v.sync()
 dt = (time.perf_counter() - t) / 3
-print(f"bf16 G={G}: {dt*1e3:.2f} ms/pass  {5.12*G/dt:.0f} xRT  {2*v.unit_macs*G/dt/1e12:.1f} TFLOP/s")
+print(f"{'bf16x3' if X3 else 'bf16'} G={G}: {dt*1e3:.2f} ms/pass  {5.12*G/dt:.0f} xRT  {2*v.unit_macs*G/dt/1e12:.1f} TFLOP/s")
 v.set_profile(True)
 v.decode_units_device(d_codes.data_ptr(), G, d_out.data_ptr(), stride); v.sync()
 prof = v.last_profile(); tot = sum(x[0] for x in prof.values())
