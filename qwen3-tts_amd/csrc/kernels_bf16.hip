@@ -260,11 +260,12 @@ __device__ __forceinline__ void conv_gemm_bf16_body(const ConvGemmArgs &a, int H
                         bf16x8 am[TN];
 #pragma unroll
                         for (int i = 0; i < TN; i++) am[i] = (wsb + (Wm - Ws))[kq * BN + i * 32];
+                        // small terms first; one term over all TN tiles at a time, so that consecutive MFMAs never
+                        // wait on each other's accumulator
 #pragma unroll
-                        for (int i = 0; i < TN; i++) {      // small terms first
-                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bv, acc[i], 0, 0, 0);
-                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bm, acc[i], 0, 0, 0);
-                        }
+                        for (int i = 0; i < TN; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bv, acc[i], 0, 0, 0);
+#pragma unroll
+                        for (int i = 0; i < TN; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bm, acc[i], 0, 0, 0);
                     }
 #pragma unroll
                     for (int i = 0; i < TN; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv, acc[i], 0, 0, 0);
