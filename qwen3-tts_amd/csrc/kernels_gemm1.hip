@@ -486,17 +486,21 @@ hipError_t launch_convs(const ConvGemmArgs &a, hipStream_t s) {
 // ===================================================================================================
 typedef __bf16 g1_bf16x8 __attribute__((ext_vector_type(8)));
 
-static constexpr int G1B_KG = 16;    // k-groups (of 8 channels) per stage
-
-template <int TN>
-__global__ __launch_bounds__(G1_NTH, 2) void gemm1_bf16_kernel(ConvGemmArgs a, int tiles_per_unit, int n_tiles) {
+// X3: the split-operand mode (ConvGemmArgs::wbm, kernels_bf16.hip): hi and mid planes of both operands in LDS, three
+// MFMAs per product in conv_gemm_bf16x3_kernel's order (mid*hi, hi*mid, hi*hi per k-group pair); half the channels
+// per stage so that the four tiles still fit.
+template <int TN, bool X3>
+__device__ __forceinline__ void gemm1_bf16_body(const ConvGemmArgs &a, int tiles_per_unit, int n_tiles) {
+    constexpr int G1B_KG = X3 ? 8 : 16;                 // k-groups (of 8 channels) per stage
     constexpr int BN = TN * 32;
     constexpr int XP = G1B_KG * G1_BM / G1_NTH;         // (k-group, position) pairs per thread and stage: 8
     constexpr int WP = G1B_KG * BN / G1_NTH;            // 16-byte weight elements per thread and stage: 2 TN
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw_all[];
     float *Pm = reinterpret_cast<float *>(smem_raw_all);                   // [4][BN]
-    uint4 *Xs = reinterpret_cast<uint4 *>(smem_raw_all + 16 * BN);         // [2][16][128]
-    uint4 *Ws = Xs + 2 * G1B_KG * G1_BM;                                   // [2][16][BN]
+    uint4 *Xs = reinterpret_cast<uint4 *>(smem_raw_all + 16 * BN);         // [2][KG][128]
+    uint4 *Ws = Xs + 2 * G1B_KG * G1_BM;                                   // [2][KG][BN]
+    uint4 *Xm = Ws + 2 * G1B_KG * BN;                                      // X3: the mid planes, same shapes
+    uint4 *Wm = Xm + 2 * G1B_KG * G1_BM;
 
     int nwg = gridDim.x, orig = blockIdx.x;
     int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
@@ -527,8 +531,9 @@ __global__ __launch_bounds__(G1_NTH, 2) void gemm1_bf16_kernel(ConvGemmArgs a, i
     const bool pos_ok = pos < a.Lin;
     const int posc = pos_ok ? pos : a.Lin - 1;
     const uint4 *wg = reinterpret_cast<const uint4 *>(a.wb);
+    const uint4 *wgm = reinterpret_cast<const uint4 *>(a.wbm);
     float xr[XP][8];
-    uint4 wr[WP];
+    uint4 wr[WP], wrm[X3 ? WP : 1];
     auto fetch = [&](int ch) {
 #pragma unroll
         for (int j = 0; j < XP; j++) {
@@ -546,23 +551,29 @@ __global__ __launch_bounds__(G1_NTH, 2) void gemm1_bf16_kernel(ConvGemmArgs a, i
             int g = ch * G1B_KG + q / BN;
             g = g < ngr ? g : 0;
             wr[j] = wg[(long)g * a.NP + n0 + q % BN];
+            if constexpr (X3) wrm[j] = wgm[(long)g * a.NP + n0 + q % BN];
         }
     };
     auto commit = [&](int ch, int buf) {
 #pragma unroll
         for (int j = 0; j < XP; j++) {
             const int c0 = (ch * G1B_KG + kg0 + 2 * j) * 8;
-            g1_bf16x8 o;
+            g1_bf16x8 o, om;
 #pragma unroll
-            for (int c = 0; c < 8; c++) o[c] = (__bf16)((pos_ok && c0 + c < a.Cin) ? xr[j][c] : 0.0f);
+            for (int c = 0; c < 8; c++) {
+                const float v = (pos_ok && c0 + c < a.Cin) ? xr[j][c] : 0.0f;
+                o[c] = (__bf16)v;
+                om[c] = (__bf16)(v - (float)o[c]);
+            }
             Xs[(buf * G1B_KG + kg0 + 2 * j) * G1_BM + t] = __builtin_bit_cast(uint4, o);
+            if constexpr (X3) Xm[(buf * G1B_KG + kg0 + 2 * j) * G1_BM + t] = __builtin_bit_cast(uint4, om);
         }
 #pragma unroll
         for (int j = 0; j < WP; j++) {
             const int q = tid + G1_NTH * j;
-            uint4 v = wr[j];
-            if (ch * G1B_KG + q / BN >= ngr) v = make_uint4(0, 0, 0, 0);
-            Ws[buf * G1B_KG * BN + q] = v;
+            const bool ok = ch * G1B_KG + q / BN < ngr;
+            Ws[buf * G1B_KG * BN + q] = ok ? wr[j] : make_uint4(0, 0, 0, 0);
+            if constexpr (X3) Wm[buf * G1B_KG * BN + q] = ok ? wrm[j] : make_uint4(0, 0, 0, 0);
         }
     };
 
@@ -576,18 +587,32 @@ __global__ __launch_bounds__(G1_NTH, 2) void gemm1_bf16_kernel(ConvGemmArgs a, i
             const g1_bf16x8 *wsb = reinterpret_cast<const g1_bf16x8 *>(Ws) + (ch & 1) * G1B_KG * BN + l31;
             const g1_bf16x8 *xsb = reinterpret_cast<const g1_bf16x8 *>(Xs) + (ch & 1) * G1B_KG * G1_BM + wave * 32 + l31;
             g1_bf16x8 av[G1B_KG / 2][TN], bv[G1B_KG / 2];
+            g1_bf16x8 am[X3 ? G1B_KG / 2 : 1][TN], bm[X3 ? G1B_KG / 2 : 1];
+            const g1_bf16x8 *wmb = wsb + (reinterpret_cast<const g1_bf16x8 *>(Wm) - reinterpret_cast<const g1_bf16x8 *>(Ws));
+            const g1_bf16x8 *xmb = xsb + (reinterpret_cast<const g1_bf16x8 *>(Xm) - reinterpret_cast<const g1_bf16x8 *>(Xs));
 #pragma unroll
             for (int sp = 0; sp < G1B_KG / 2; sp++) {
                 const int kq = 2 * sp + h;
                 bv[sp] = xsb[kq * G1_BM];
+                if constexpr (X3) bm[sp] = xmb[kq * G1_BM];
 #pragma unroll
-                for (int i = 0; i < TN; i++) av[sp][i] = wsb[kq * BN + i * 32];
+                for (int i = 0; i < TN; i++) {
+                    av[sp][i] = wsb[kq * BN + i * 32];
+                    if constexpr (X3) am[sp][i] = wmb[kq * BN + i * 32];
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int sp = 0; sp < G1B_KG / 2; sp++)
+            for (int sp = 0; sp < G1B_KG / 2; sp++) {
+                if constexpr (X3) {
+#pragma unroll
+                    for (int i = 0; i < TN; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[sp][i], bv[sp], acc[i], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < TN; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[sp][i], bm[sp], acc[i], 0, 0, 0);
+                }
 #pragma unroll
                 for (int i = 0; i < TN; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[sp][i], bv[sp], acc[i], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         commit(nx, (ch + 1) & 1);
@@ -603,8 +628,17 @@ __global__ __launch_bounds__(G1_NTH, 2) void gemm1_bf16_kernel(ConvGemmArgs a, i
     for (int i = 0; i < TN; i++) conv_epilogue_tile<BN>(a, acc[i], Pm, n0, i * 32 + 4 * h, m, yu, ru, y2u);
 }
 
+template <int TN>
+__global__ __launch_bounds__(G1_NTH, 2) void gemm1_bf16_kernel(ConvGemmArgs a, int tiles_per_unit, int n_tiles) {
+    gemm1_bf16_body<TN, false>(a, tiles_per_unit, n_tiles);
+}
+template <int TN>
+__global__ __launch_bounds__(G1_NTH, 2) void gemm1_bf16x3_kernel(ConvGemmArgs a, int tiles_per_unit, int n_tiles) {
+    gemm1_bf16_body<TN, true>(a, tiles_per_unit, n_tiles);
+}
+
 static bool g1b_supported(const ConvGemmArgs &a) {
-    return a.wb && !a.wbm && !a.wb2 && !a.w2 && !a.xb && !a.yb && a.y && a.ntaps == 1 && a.shift0 == 0 && a.S == 1 && !a.sn_a &&
+    return a.wb && (!a.wbm || !((uintptr_t)a.wbm & 15)) && !a.wb2 && !a.w2 && !a.xb && !a.yb && a.y && a.ntaps == 1 && a.shift0 == 0 && a.S == 1 && !a.sn_a &&
            !a.in_elu && a.s2d <= 1 && !((uintptr_t)a.wb & 15) && a.TN >= 1 && a.TN <= 4 && !(a.NP % (32 * a.TN)) &&
            a.NP >= a.N && a.Lin >= 1 && a.act != ACT_ELU && a.act != ACT_GELU_TANH && (!a.y2 || (a.psn_a && a.psn_ib));
 }
@@ -629,22 +663,30 @@ const char *gemm1_bf16_kernel_name(const ConvGemmArgs &a) {
     static char names[8][32];
     const int tn = g1b_tn(a);
     char *n = names[tn & 7];
+    if (a.wbm) {
+        static char n3[8][32];
+        char *m = n3[tn & 7];
+        if (!m[0]) snprintf(m, 32, "gemm1_bf16x3_kernel<%d>", tn);
+        return m;
+    }
     if (!n[0]) snprintf(n, 32, "gemm1_bf16_kernel<%d>", tn);
     return n;
 }
 
-template <int TN>
+template <int TN, bool X3>
 static hipError_t gemm1_bf16_launch_one(const ConvGemmArgs &a, int tiles_per_unit, int n_tiles, long grid, size_t lds, hipStream_t s) {
     static bool done[64] = {};
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 64 && !done[dev]) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm1_bf16_kernel<TN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        e = X3 ? hipFuncSetAttribute(reinterpret_cast<const void *>(gemm1_bf16x3_kernel<TN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+               : hipFuncSetAttribute(reinterpret_cast<const void *>(gemm1_bf16_kernel<TN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         done[dev] = true;
     }
-    hipLaunchKernelGGL((gemm1_bf16_kernel<TN>), dim3((unsigned)grid), dim3(G1_NTH), lds, s, a, tiles_per_unit, n_tiles);
+    if constexpr (X3) hipLaunchKernelGGL((gemm1_bf16x3_kernel<TN>), dim3((unsigned)grid), dim3(G1_NTH), lds, s, a, tiles_per_unit, n_tiles);
+    else hipLaunchKernelGGL((gemm1_bf16_kernel<TN>), dim3((unsigned)grid), dim3(G1_NTH), lds, s, a, tiles_per_unit, n_tiles);
     return hipGetLastError();
 }
 
@@ -656,12 +698,13 @@ hipError_t launch_gemm1_bf16(const ConvGemmArgs &a, hipStream_t s) {
     const int n_tiles = a.NP / (32 * tn);
     const long grid = (long)tiles_per_unit * a.units * n_tiles;
     if (grid > 0x7fffffffL) return hipErrorInvalidValue;
-    const size_t lds = 16 * 32 * (size_t)tn + 16 * 2 * G1B_KG * (G1_BM + 32 * (size_t)tn);
+    // plain: 16 k-groups per stage, one plane; split-operand: 8 k-groups, two planes -- the same bytes
+    const size_t lds = 16 * 32 * (size_t)tn + 16 * 2 * 16 * (G1_BM + 32 * (size_t)tn);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    switch (tn) {
-        case 1: return gemm1_bf16_launch_one<1>(a, tiles_per_unit, n_tiles, grid, lds, s);
-        default: return gemm1_bf16_launch_one<2>(a, tiles_per_unit, n_tiles, grid, lds, s);
-    }
+    if (a.wbm) return tn == 1 ? gemm1_bf16_launch_one<1, true>(a, tiles_per_unit, n_tiles, grid, lds, s)
+                              : gemm1_bf16_launch_one<2, true>(a, tiles_per_unit, n_tiles, grid, lds, s);
+    return tn == 1 ? gemm1_bf16_launch_one<1, false>(a, tiles_per_unit, n_tiles, grid, lds, s)
+                   : gemm1_bf16_launch_one<2, false>(a, tiles_per_unit, n_tiles, grid, lds, s);
 }
 
 // ===================================================================================================
@@ -671,8 +714,10 @@ hipError_t launch_gemm1_bf16(const ConvGemmArgs &a, hipStream_t s) {
 // cover each other's waits; products in conv_gemm_bf16_kernel's order (channel block of 32, tap, k-group pair).
 // XB: packed bf16 input (ConvGemmArgs::xb); otherwise channel-first fp32 without an input activation.
 // ===================================================================================================
-template <bool XB>
-__global__ __launch_bounds__(G1_NTH, XB ? 3 : 2) void convs_bf16_kernel(ConvGemmArgs a, int HL, int XW, int tiles_per_unit, int n_tiles) {
+// X3 (fp32 input only): the split-operand mode, both planes of both operands in LDS (104 KB: one workgroup per CU).
+template <bool XB, bool X3>
+__device__ __forceinline__ void convs_bf16_body(const ConvGemmArgs &a, int HL, int XW, int tiles_per_unit, int n_tiles) {
+    static_assert(!(XB && X3), "the split-operand mode exchanges fp32 tensors");
     constexpr int BN = 32, KG = 8;                      // one 32-row tile; k-groups (of 8 channels) per stage
     constexpr int XPM = 6;                              // (k-group, position) pairs per thread and stage (host checks)
     constexpr int WPM = 7;                              // 16-byte weight elements per thread: 2 blocks x ntaps <= 7 x 4 x 32 / 256
@@ -680,6 +725,10 @@ __global__ __launch_bounds__(G1_NTH, XB ? 3 : 2) void convs_bf16_kernel(ConvGemm
     float *Pm = reinterpret_cast<float *>(smem_raw_all);                   // [4][BN]
     uint4 *Xs = reinterpret_cast<uint4 *>(smem_raw_all + 16 * BN);         // [KG][XW]
     uint4 *Ws = Xs + KG * XW;                                              // [2][ntaps][4][BN]
+    uint4 *Xm = Ws + 2 * a.ntaps * 4 * BN;                                 // X3: the mid planes, same shapes
+    uint4 *Wm = Xm + KG * XW;
+    // fp32 input with an input SnakeBeta: exp(alpha) | 1/(exp(beta)+1e-9) per channel, [2][8 * k-groups]
+    float *Sn = reinterpret_cast<float *>(X3 ? Wm + 2 * a.ntaps * 4 * BN : Xm);
 
     int nwg = gridDim.x, orig = blockIdx.x;
     int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
@@ -698,6 +747,12 @@ __global__ __launch_bounds__(G1_NTH, XB ? 3 : 2) void convs_bf16_kernel(ConvGemm
     const int wtot = 2 * a.ntaps * 4 * BN;              // weight elements per stage
 
     fill_param_table<BN, false>(a, Pm, n0, tid, G1_NTH);
+    if (!XB && a.sn_a) {                                // (read at the first commit, behind the loop's first barrier)
+        for (int i = tid; i < ngr * 8; i += G1_NTH) {
+            Sn[i] = i < a.Cin ? a.sn_a[i] : 0.0f;
+            Sn[ngr * 8 + i] = i < a.Cin ? a.sn_ib[i] : 0.0f;
+        }
+    }
 
     f32x16 acc;
 #pragma unroll
@@ -721,7 +776,8 @@ __global__ __launch_bounds__(G1_NTH, XB ? 3 : 2) void convs_bf16_kernel(ConvGemm
     }
     const uint4 *xq = reinterpret_cast<const uint4 *>(a.xb);
     const uint4 *wg = reinterpret_cast<const uint4 *>(a.wb);
-    uint4 xr[XPM], wr[WPM];
+    const uint4 *wgm = reinterpret_cast<const uint4 *>(a.wbm);
+    uint4 xr[XPM], wr[WPM], wrm[X3 ? WPM : 1];
     float xf[XB ? 1 : XPM][8];
     auto fetch = [&](int st) {
 #pragma unroll
@@ -745,7 +801,9 @@ __global__ __launch_bounds__(G1_NTH, XB ? 3 : 2) void convs_bf16_kernel(ConvGemm
             const int cbi = slab / a.ntaps, tap = slab - cbi * a.ntaps;
             const int cb = 2 * st + cbi;
             const bool ok = q < wtot && cb < ncb;
-            wr[j] = wg[ok ? ((long)(tap * ncb + cb) * 4 + rem / BN) * a.NP + n0 + rem % BN : 0];
+            const long wi = ok ? ((long)(tap * ncb + cb) * 4 + rem / BN) * a.NP + n0 + rem % BN : 0;
+            wr[j] = wg[wi];
+            if constexpr (X3) wrm[j] = wgm[wi];
         }
     };
     auto commit = [&](int st) {
@@ -758,10 +816,28 @@ __global__ __launch_bounds__(G1_NTH, XB ? 3 : 2) void convs_bf16_kernel(ConvGemm
                 v = xr[j];
                 if (!pok || st * KG + xg[j] >= ngr) v = make_uint4(0, 0, 0, 0);
             } else {
-                g1_bf16x8 o;
+                g1_bf16x8 o, om;
+                float f[8];
 #pragma unroll
-                for (int c = 0; c < 8; c++) o[c] = (__bf16)((pok && (st * KG + xg[j]) * 8 + c < a.Cin) ? xf[j][c] : 0.0f);
+                for (int c = 0; c < 8; c++) f[c] = (pok && (st * KG + xg[j]) * 8 + c < a.Cin) ? xf[j][c] : 0.0f;
+                if (a.sn_a) {           // as conv_gemm_bf16_kernel's commit: packed evaluation on channel pairs
+                    const int c0 = (st * KG + xg[j]) * 8;
+                    const float4 *sa = reinterpret_cast<const float4 *>(Sn + (c0 < ngr * 8 ? c0 : 0));
+                    const float4 *sb = reinterpret_cast<const float4 *>(Sn + ngr * 8 + (c0 < ngr * 8 ? c0 : 0));
+                    const float4 a0 = sa[0], a1 = sa[1], b0 = sb[0], b1 = sb[1];
+                    const f32x2 p0 = snake_beta2(mk2(f[0], f[1]), mk2(a0.x, a0.y), mk2(b0.x, b0.y));
+                    const f32x2 p1 = snake_beta2(mk2(f[2], f[3]), mk2(a0.z, a0.w), mk2(b0.z, b0.w));
+                    const f32x2 p2 = snake_beta2(mk2(f[4], f[5]), mk2(a1.x, a1.y), mk2(b1.x, b1.y));
+                    const f32x2 p3 = snake_beta2(mk2(f[6], f[7]), mk2(a1.z, a1.w), mk2(b1.z, b1.w));
+                    f[0] = p0.x; f[1] = p0.y; f[2] = p1.x; f[3] = p1.y; f[4] = p2.x; f[5] = p2.y; f[6] = p3.x; f[7] = p3.y;
+                }
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    o[c] = (__bf16)f[c];
+                    om[c] = (__bf16)(f[c] - (float)o[c]);
+                }
                 v = __builtin_bit_cast(uint4, o);
+                if constexpr (X3) Xm[tid + G1_NTH * j] = __builtin_bit_cast(uint4, om);
             }
             Xs[tid + G1_NTH * j] = v;
         }
@@ -770,9 +846,9 @@ __global__ __launch_bounds__(G1_NTH, XB ? 3 : 2) void convs_bf16_kernel(ConvGemm
             const int q = tid + G1_NTH * j;
             if (q >= wtot) continue;
             const int cbi = (q / (4 * BN)) / a.ntaps;
-            uint4 v = wr[j];
-            if (2 * st + cbi >= ncb) v = make_uint4(0, 0, 0, 0);
-            Ws[q] = v;
+            const bool ok = 2 * st + cbi < ncb;
+            Ws[q] = ok ? wr[j] : make_uint4(0, 0, 0, 0);
+            if constexpr (X3) Wm[q] = ok ? wrm[j] : make_uint4(0, 0, 0, 0);
         }
     };
 
@@ -790,8 +866,21 @@ __global__ __launch_bounds__(G1_NTH, XB ? 3 : 2) void convs_bf16_kernel(ConvGemm
                 const g1_bf16x8 *xs = xsb + cbi * 4 * XW + tap * a.shift_step;
                 g1_bf16x8 b0 = xs[h * XW], b1 = xs[(2 + h) * XW];
                 g1_bf16x8 a0 = ws[h * BN], a1 = ws[(2 + h) * BN];
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc, 0, 0, 0);
+                if constexpr (X3) {     // per k-group pair: mid*hi, hi*mid, hi*hi (conv_gemm_bf16x3_kernel's order)
+                    const g1_bf16x8 *xm = xs + (reinterpret_cast<const g1_bf16x8 *>(Xm) - reinterpret_cast<const g1_bf16x8 *>(Xs));
+                    const g1_bf16x8 *wm = ws + (reinterpret_cast<const g1_bf16x8 *>(Wm) - reinterpret_cast<const g1_bf16x8 *>(Ws));
+                    g1_bf16x8 bm0 = xm[h * XW], bm1 = xm[(2 + h) * XW];
+                    g1_bf16x8 am0 = wm[h * BN], am1 = wm[(2 + h) * BN];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am0, b0, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bm0, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am1, b1, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bm1, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc, 0, 0, 0);
+                } else {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc, 0, 0, 0);
+                }
             }
     }
 
@@ -806,8 +895,17 @@ __global__ __launch_bounds__(G1_NTH, XB ? 3 : 2) void convs_bf16_kernel(ConvGemm
     conv_epilogue_tile<BN>(a, acc, Pm, n0, 4 * h, m, yu, ru, y2u, ybu);
 }
 
+template <bool XB>
+__global__ __launch_bounds__(G1_NTH, XB ? 3 : 2) void convs_bf16_kernel(ConvGemmArgs a, int HL, int XW, int tiles_per_unit, int n_tiles) {
+    convs_bf16_body<XB, false>(a, HL, XW, tiles_per_unit, n_tiles);
+}
+__global__ __launch_bounds__(G1_NTH, 2) void convs_bf16x3_kernel(ConvGemmArgs a, int HL, int XW, int tiles_per_unit, int n_tiles) {
+    convs_bf16_body<false, true>(a, HL, XW, tiles_per_unit, n_tiles);
+}
+
 static bool convs_bf16_supported(const ConvGemmArgs &a) {
-    if (!(a.wb && !a.wbm && !a.wb2 && !a.w2 && a.ntaps >= 5 && a.ntaps <= 7 && a.S >= 1 && !a.in_elu && a.s2d <= 1 && !a.sn_a &&
+    if (a.wbm && (a.xb || a.yb || ((uintptr_t)a.wbm & 15))) return false;
+    if (!(a.wb && !a.wb2 && !a.w2 && a.ntaps >= 5 && a.ntaps <= 7 && a.S >= 1 && !a.in_elu && a.s2d <= 1 && !(a.xb && a.sn_a) &&
           !((uintptr_t)a.wb & 15) && !(a.NP % 32) && a.NP >= a.N && a.Lin >= 1 && a.act != ACT_ELU && a.act != ACT_GELU_TANH &&
           (a.y || a.yb) && (!a.y2 || (a.psn_a && a.psn_ib && !a.yb))))
         return false;
@@ -827,7 +925,22 @@ bool convs_bf16_selected(const ConvGemmArgs &a) {
 }
 
 const char *convs_bf16_kernel_name(const ConvGemmArgs &a) {
+    if (a.wbm) return "convs_bf16x3_kernel";
     return a.xb ? "convs_bf16_kernel<true>" : "convs_bf16_kernel<false>";
+}
+
+static hipError_t convs_bf16x3_launch(const ConvGemmArgs &a, int HL, int XW, int tiles_per_unit, int n_tiles, long grid, size_t lds, hipStream_t s) {
+    static bool done[64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64 && !done[dev]) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(convs_bf16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        done[dev] = true;
+    }
+    hipLaunchKernelGGL(convs_bf16x3_kernel, dim3((unsigned)grid), dim3(G1_NTH), lds, s, a, HL, XW, tiles_per_unit, n_tiles);
+    return hipGetLastError();
 }
 
 template <bool XB>
@@ -854,8 +967,10 @@ hipError_t launch_convs_bf16(const ConvGemmArgs &a, hipStream_t s) {
     const int n_tiles = a.NP / 32;
     const long grid = (long)tiles_per_unit * a.units * n_tiles;
     if (grid > 0x7fffffffL) return hipErrorInvalidValue;
-    const size_t lds = 16 * 32 + 16 * ((size_t)8 * XW + (size_t)2 * a.ntaps * 4 * 32);
+    const size_t lds = 16 * 32 + (a.wbm ? 2 : 1) * 16 * ((size_t)8 * XW + (size_t)2 * a.ntaps * 4 * 32) +
+                       ((!a.xb && a.sn_a) ? 2 * sizeof(float) * 8 * (size_t)((a.Cin + 7) / 8) : 0);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
+    if (a.wbm) return convs_bf16x3_launch(a, HL, XW, tiles_per_unit, n_tiles, grid, lds, s);
     return a.xb ? convs_bf16_launch_one<true>(a, HL, XW, tiles_per_unit, n_tiles, grid, lds, s)
                 : convs_bf16_launch_one<false>(a, HL, XW, tiles_per_unit, n_tiles, grid, lds, s);
 }

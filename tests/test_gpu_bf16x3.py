@@ -116,3 +116,26 @@ def test_x3_full_size_unit_independence(pkg, synth):
     utts = [synth.make_codes(125, 1000 + u, cfg) for u in range(3)]
     for got, c in zip(v.synthesize_batch(utts), utts):
         assert np.array_equal(got, v.synthesize(c))
+
+
+@pytest.mark.parametrize("cfg_name,unit,frames", [("FULL", 64, 125), ("ODD", 9, 20), ("SMALL", 8, 13)])
+def test_x3_small_launch_kernels_bitwise(pkg, synth, cfg_name, unit, frames, monkeypatch):
+    """The small-launch forms (gemm1_bf16x3_kernel, convs_bf16x3_kernel) make conv_gemm_bf16x3_kernel's MFMA chains:
+    forced on everywhere vs off, the waveform is the same bit for bit."""
+    cfg = getattr(synth, cfg_name)
+    path = os.path.join(tempfile.gettempdir(), f"hipvoc_test_{cfg_name}_0.safetensors")
+    if not os.path.exists(path):
+        synth.save_safetensors(path, weights_for(synth, cfg_name, 0), cfg.metadata())
+    codes = synth.make_codes(frames, 31, cfg)
+    outs = []
+    for wgs in ("0", "1000000"):
+        monkeypatch.setenv("HIPVOC_GEMM1_WGS", wgs)
+        monkeypatch.setenv("HIPVOC_CONVS_WGS", wgs)
+        v = pkg.HipVocoder.load(path, device=0, unit_frames=unit, dtype=BF16X3)
+        v.set_profile(True)
+        outs.append(v.synthesize(codes))
+        for name in ("gemm1_bf16x3_kernel", "convs_bf16x3_kernel")[: 2 if cfg_name == "FULL" else 1]:
+            used = any(name in k for k in v.last_profile())
+            assert used == (wgs != "0"), (wgs, name, sorted(v.last_profile()))
+        del v
+    assert outs[0].size and np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))

@@ -12,7 +12,7 @@ cfg = synth.FULL
 path = os.path.join(tempfile.gettempdir(), "hipvoc_prof_full.safetensors")
 if not os.path.exists(path):
     synth.save_safetensors(path, synth.make_weights(cfg, 0), cfg.metadata())
-for dtype in (0, 1):
+for dtype in (0, 1, 2):          # fp32, bf16, bf16x3
     v = pkg.HipVocoder.load(path, unit_frames=64, dtype=dtype)
     codes = synth.make_codes(125, 1000, cfg)
     for _ in range(3):
