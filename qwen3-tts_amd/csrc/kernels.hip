@@ -751,25 +751,37 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const float *qkv, fl
     const float scaling = 1.0f / sqrtf((float)HD);
     const int k_lo = max(0, q0 - window + 1);
     const int qlast = min(q0 + 31, T - 1);
-    for (int kt = k_lo / 32; kt <= qlast / 32; kt++) {
-        __syncthreads();                                   // the previous tile's LDS reads are done
-        {
-            const int key = kt * 32 + l31;
-            const int kc = key < T ? key : T - 1;          // clamped: keys >= T are masked below
+    // The next key tile (k, v, RoPE factors: 3 HD / 2 + HD / 2 values per lane) is fetched into registers while the
+    // current one is being multiplied: a tile's loads are one memory round trip, about what its MFMAs take.
+    float ka[HD / 4], kb[HD / 4], kcs[HD / 4], ksn[HD / 4], vv[HD / 2];
+    auto tile_fetch = [&](int kt) {
+        const int key = kt * 32 + l31;
+        const int kc = key < T ? key : T - 1;              // clamped: keys >= T are masked below
 #pragma unroll
-            for (int j = 0; j < HD / 4; j++) {
-                const int d = h * (HD / 4) + j;
-                const float a = kp[(long)d * cs + kc], b = kp[(long)(d + half) * cs + kc];
-                const float c = cos_t[kc * half + d], s = sin_t[kc * half + d];
-                Ks[d][l31] = a * c + (-b) * s;
-                Ks[d + half][l31] = b * c + a * s;
-            }
-#pragma unroll
-            for (int j = 0; j < HD / 2; j++) {
-                const int d = h * (HD / 2) + j;
-                Vs[l31][d] = vp[(long)d * cs + kc];
-            }
+        for (int j = 0; j < HD / 4; j++) {
+            const int d = h * (HD / 4) + j;
+            ka[j] = kp[(long)d * cs + kc];
+            kb[j] = kp[(long)(d + half) * cs + kc];
+            kcs[j] = cos_t[kc * half + d];
+            ksn[j] = sin_t[kc * half + d];
         }
+#pragma unroll
+        for (int j = 0; j < HD / 2; j++) vv[j] = vp[(long)(h * (HD / 2) + j) * cs + kc];
+    };
+    const int kt_last = qlast / 32;
+    tile_fetch(k_lo / 32);
+    for (int kt = k_lo / 32; kt <= kt_last; kt++) {
+        __syncthreads();                                   // the previous tile's LDS reads are done
+#pragma unroll
+        for (int j = 0; j < HD / 4; j++) {
+            const int d = h * (HD / 4) + j;
+            const float a = ka[j], b = kb[j], c = kcs[j], s = ksn[j];
+            Ks[d][l31] = a * c + (-b) * s;
+            Ks[d + half][l31] = b * c + a * s;
+        }
+#pragma unroll
+        for (int j = 0; j < HD / 2; j++) Vs[l31][h * (HD / 2) + j] = vv[j];
+        tile_fetch(kt < kt_last ? kt + 1 : kt);            // unconditional (the last tile re-fetches itself)
         __syncthreads();
         f32x16 sc;
 #pragma unroll
