@@ -499,16 +499,27 @@ __global__ __launch_bounds__(256) void rvq_kernel(RvqArgs a) {
     int u = blockIdx.x / a.T, t = blockIdx.x - u * a.T;
     const long long *cp = a.codes + ((long)u * a.T + t) * a.nq;
     for (int d = threadIdx.x; d < a.D; d += blockDim.x) {
+        // (four rows' loads in flight at a time, summed in codebook order: the kernel is one dependent round trip per
+        // loop iteration otherwise -- 0.12 ms for a single utterance)
         float v0 = 0.0f, v1 = 0.0f;
-        for (int q = 0; q < a.nq; q++) {
-            long long c = cp[q];
-            if (c < 0 || c >= a.cb_size) {
-                if (d == 0) *a.err = 1;
-                c = 0;
+        for (int q0 = 0; q0 < a.nq; q0 += 4) {
+            float e[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int q = q0 + j < a.nq ? q0 + j : a.nq - 1;      // clamped: the copy is not summed
+                long long c = cp[q];
+                if (c < 0 || c >= a.cb_size) {
+                    if (d == 0) *a.err = 1;
+                    c = 0;
+                }
+                e[j] = a.embed[((long)q * a.cb_size + c) * a.D + d];
             }
-            float e = a.embed[((long)q * a.cb_size + c) * a.D + d];
-            if (q == 0) v0 = 0.0f + e;
-            else v1 = v1 + e;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int q = q0 + j;
+                if (q == 0) v0 = 0.0f + e[j];
+                else if (q < a.nq) v1 = v1 + e[j];
+            }
         }
         s0[d] = v0;
         s1[d] = v1;
@@ -519,9 +530,23 @@ __global__ __launch_bounds__(256) void rvq_kernel(RvqArgs a) {
     }
     __syncthreads();
     for (int n = threadIdx.x; n < a.Q; n += blockDim.x) {
+        // the two chains keep their k-ascending order; eight weights of each are loaded before they are used
         float p = 0.0f, r = 0.0f;
-        for (int k = 0; k < a.D; k++) p = __builtin_fmaf(a.wf_t[(long)k * a.Q + n], s0[k], p);
-        for (int k = 0; k < a.D; k++) r = __builtin_fmaf(a.wr_t[(long)k * a.Q + n], s1[k], r);
+        int k = 0;
+        for (; k + 8 <= a.D; k += 8) {
+            float wf[8], wr[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                wf[j] = a.wf_t[(long)(k + j) * a.Q + n];
+                wr[j] = a.wr_t[(long)(k + j) * a.Q + n];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) p = __builtin_fmaf(wf[j], s0[k + j], p);
+#pragma unroll
+            for (int j = 0; j < 8; j++) r = __builtin_fmaf(wr[j], s1[k + j], r);
+        }
+        for (int kk = k; kk < a.D; kk++) p = __builtin_fmaf(a.wf_t[(long)kk * a.Q + n], s0[kk], p);
+        for (int kk = k; kk < a.D; kk++) r = __builtin_fmaf(a.wr_t[(long)kk * a.Q + n], s1[kk], r);
         a.out[(long)n * a.G * a.Lp + (long)u * a.Lp + t] = p + r;
     }
 }
