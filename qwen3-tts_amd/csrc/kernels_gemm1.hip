@@ -155,9 +155,9 @@ __global__ __launch_bounds__(G1_NTH, 2) void gemm1_kernel(ConvGemmArgs a, int ti
 // ---------------------------------------------------------------------------------------------------
 static bool g1_enc(const ConvGemmArgs &a) { return a.act == ACT_ELU || a.act == ACT_GELU_TANH; }
 
-// what the kernel supports: fp32, one tap at shift 0, stride-1 rows, no input activation, no fusion, no s2d
+// what the kernel supports: fp32, one tap at shift 0 (plain or transposed: rows = channels x phases), no input activation, no fusion, no s2d
 static bool g1_supported(const ConvGemmArgs &a) {
-    return a.w && !a.wb && !a.w2 && !a.wb2 && !a.xb && !a.yb && a.ntaps == 1 && a.shift0 == 0 && a.S == 1 && !a.sn_a &&
+    return a.w && !a.wb && !a.w2 && !a.wb2 && !a.xb && !a.yb && a.ntaps == 1 && a.shift0 == 0 && a.S >= 1 && !a.sn_a &&
            !a.in_elu && a.s2d <= 1 && !(a.x_cs & 3) && !(a.x_us & 3) && !((uintptr_t)a.x & 15) && !((uintptr_t)a.w & 15) &&
            a.TN >= 1 && a.TN <= 4 && !(a.NP % (32 * a.TN)) && a.NP >= a.N && a.Lin >= 1 && (!a.y2 || (a.psn_a && a.psn_ib));
 }
@@ -638,7 +638,7 @@ __global__ __launch_bounds__(G1_NTH, 2) void gemm1_bf16x3_kernel(ConvGemmArgs a,
 }
 
 static bool g1b_supported(const ConvGemmArgs &a) {
-    return a.wb && (!a.wbm || !((uintptr_t)a.wbm & 15)) && !a.wb2 && !a.w2 && !a.xb && !a.yb && a.y && a.ntaps == 1 && a.shift0 == 0 && a.S == 1 && !a.sn_a &&
+    return a.wb && (!a.wbm || !((uintptr_t)a.wbm & 15)) && !a.wb2 && !a.w2 && !a.xb && !a.yb && a.y && a.ntaps == 1 && a.shift0 == 0 && a.S >= 1 && !a.sn_a &&
            !a.in_elu && a.s2d <= 1 && !((uintptr_t)a.wb & 15) && a.TN >= 1 && a.TN <= 4 && !(a.NP % (32 * a.TN)) &&
            a.NP >= a.N && a.Lin >= 1 && a.act != ACT_ELU && a.act != ACT_GELU_TANH && (!a.y2 || (a.psn_a && a.psn_ib));
 }
