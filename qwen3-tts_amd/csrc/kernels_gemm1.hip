@@ -410,7 +410,7 @@ __global__ __launch_bounds__(G1_NTH, (CB == 1 && TN == 1) ? 3 : 2) void convs_ke
     for (int i = 0; i < TN; i++) conv_epilogue_tile<BN, false>(a, acc[i], Pm, n0, i * 32 + 4 * h, m, yu, ru, y2u);
 }
 
-static int convs_cb(const ConvGemmArgs &a) { return a.ntaps >= 5 ? 1 : 4; }
+static int convs_cb(const ConvGemmArgs &a) { return a.ntaps >= 5 ? 1 : 2; }     // 3- and 4-tap convs: two channel blocks per stage
 static int convs_tn(const ConvGemmArgs &a) {       // CB = 4 keeps ten float4 of X in flight: one tile of 32 rows only
     if (convs_cb(a) != 1) return 1;
     const int tn = g1_tn(a);
@@ -418,7 +418,7 @@ static int convs_tn(const ConvGemmArgs &a) {       // CB = 4 keeps ten float4 of
 }
 
 static bool convs_supported(const ConvGemmArgs &a) {
-    if (!(a.w && !a.wb && !a.w2 && !a.wb2 && !a.xb && !a.yb && a.ntaps >= 5 && a.ntaps <= 8 && a.S >= 1 && !a.in_elu &&
+    if (!(a.w && !a.wb && !a.w2 && !a.wb2 && !a.xb && !a.yb && a.ntaps >= 3 && a.ntaps <= 8 && a.S >= 1 && !a.in_elu &&
           a.s2d <= 1 && a.act != ACT_ELU && a.act != ACT_GELU_TANH && !(a.x_cs & 3) && !(a.x_us & 3) &&
           !((uintptr_t)a.x & 15) && !((uintptr_t)a.w & 15) && a.TN >= 1 && a.TN <= 4 && !(a.NP % (32 * a.TN)) &&
           a.NP >= a.N && a.Lin >= 1 && (!a.y2 || (a.psn_a && a.psn_ib))))
@@ -474,6 +474,7 @@ hipError_t launch_convs(const ConvGemmArgs &a, hipStream_t s) {
     if (grid > 0x7fffffffL) return hipErrorInvalidValue;
     const size_t lds = sizeof(float) * (4 * 32 * (size_t)tn + 2 * (size_t)cb * 16 * XW + 2 * (size_t)cb * a.ntaps * 16 * 32 * tn);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
+    if (cb == 2) return convs_launch_one<1, 2>(a, HL, XW, tiles_per_unit, n_tiles, grid, lds, s);
     return tn == 1 ? convs_launch_one<1, 1>(a, HL, XW, tiles_per_unit, n_tiles, grid, lds, s)
                    : convs_launch_one<2, 1>(a, HL, XW, tiles_per_unit, n_tiles, grid, lds, s);
 }
