@@ -594,11 +594,12 @@ __global__ __launch_bounds__(256) void rmsnorm_reg_kernel(const float *x, float 
     long p = (long)blockIdx.x * 32 + lp;
     bool ok = p < P;
     long pc = ok ? p : P - 1;
-    float v[NPT];
+    float v[NPT], wv[NPT];        // (the weights travel with the first batch of loads: no second round trip after the barrier)
 #pragma unroll
     for (int j = 0; j < NPT; j++) {
         int c = sl + 8 * j;
         v[j] = c < C ? x[(long)c * P + pc] : 0.0f;
+        wv[j] = c < C ? w[c] : 0.0f;
     }
     float ss = 0.0f;
 #pragma unroll
@@ -612,7 +613,7 @@ __global__ __launch_bounds__(256) void rmsnorm_reg_kernel(const float *x, float 
 #pragma unroll
     for (int j = 0; j < NPT; j++) {
         int c = sl + 8 * j;
-        if (ok && c < C) y[(long)c * P + p] = w[c] * (v[j] * r);
+        if (ok && c < C) y[(long)c * P + p] = wv[j] * (v[j] * r);
     }
 }
 
