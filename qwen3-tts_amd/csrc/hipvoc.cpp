@@ -26,6 +26,7 @@
 
 #include "kernels.h"
 #include "safetensors.hpp"
+#include "scratch.h"
 
 namespace hipvoc {
 
@@ -91,6 +92,7 @@ struct Plan {
     int G = 0, T = 0;
     std::vector<Step> steps;
     float *enc_audio = nullptr;    // encoder plans: the input buffer this plan's first step reads
+    size_t scratch_used = 0;       // plans of the allocation-free entry point: bytes of the static scratch array they carve up
 };
 
 struct EncModel;      // encoder.inc.cpp
@@ -141,6 +143,11 @@ struct Ctx {
     std::map<int, std::pair<float *, size_t>> bufs;
     bool ws_frozen = false;
     std::map<std::pair<int, int>, std::unique_ptr<Plan>> plans;
+    // hipvoc_decode_units_device_noalloc: this device's copy of the static scratch array (scratch.hip) and the plans
+    // whose workspace is carved out of it
+    void *scratch = nullptr;
+    size_t scratch_bytes = 0;
+    std::map<std::pair<int, int>, std::unique_ptr<Plan>> scratch_plans;
 
     // per-call bindings read by the plan's first/last steps
     const long long *cur_codes = nullptr;
@@ -591,9 +598,26 @@ struct PlanBuilder {
     Plan *p;
     int G, T;
     bool fail = false;
+    char *sbase = nullptr;         // non-null: carve the workspace out of the static scratch array instead of c->bufs
+    size_t soff = 0, scap = 0;
+    std::map<int, std::pair<float *, size_t>> sbufs;
 
     float *buf(int id, size_t floats) {
         floats = (size_t)rupl((long)floats + 64, 64);
+        if (sbase) {
+            auto f = sbufs.find(id);
+            if (f != sbufs.end() && f->second.second >= floats) return f->second.first;
+            const size_t bytes = (size_t)rupl((long)(floats * sizeof(float)), 256);
+            if (soff + bytes > scap) {
+                soff += bytes;         // keep counting: the error text states the whole need
+                fail = true;
+                return nullptr;
+            }
+            float *ptr = reinterpret_cast<float *>(sbase + soff);
+            soff += bytes;
+            sbufs[id] = {ptr, floats};
+            return ptr;
+        }
         auto it = c->bufs.find(id);
         if (it != c->bufs.end() && it->second.second >= floats) return it->second.first;
         if (c->ws_frozen) {
@@ -669,13 +693,19 @@ struct PlanBuilder {
     }
 };
 
-static Plan *get_plan(Ctx *c, int G, int T, bool debug = false) {
-    auto key = std::make_pair(debug ? -G : G, T);
-    auto it = c->plans.find(key);
-    if (it != c->plans.end()) return it->second.get();
+// Builds the launch plan of one pass over G units of T frames.  sbase == null: workspace from the handle's hipMalloc'ed
+// buffers (c->bufs); else carved out of [sbase, sbase + scap) -- the static scratch array -- with *used = bytes needed
+// (counted past scap too, so a failed build still reports the whole need).
+static std::unique_ptr<Plan> build_plan(Ctx *c, int G, int T, bool debug, char *sbase, size_t scap, size_t *used) {
     std::unique_ptr<Plan> plan(new Plan);
     plan->G = G; plan->T = T;
     PlanBuilder b{c, plan.get(), G, T};
+    b.sbase = sbase;
+    b.scap = scap;
+    struct Used {          // every exit path reports the bytes counted so far
+        PlanBuilder &b; size_t *used;
+        ~Used() { if (used) *used = b.soff; }
+    } report{b, used};
     int st = 0;
     const int Tp = rup(T, 4);
     // g1 RVQ
@@ -738,14 +768,15 @@ static Plan *get_plan(Ctx *c, int G, int T, bool debug = false) {
         return c->fuse_res && PlanBuilder::can_fuse(blk.res[0].c1, blk.res[0].c2) &&
                PlanBuilder::can_fuse(blk.res[1].c1, blk.res[1].c2) && PlanBuilder::can_fuse(blk.res[2].c1, blk.res[2].c2);
     };
-    size_t big = 0, snk_floats = 0;
+    size_t big = 0, big2 = 0, snk_floats = 0;      // big2: the third buffer only ever holds a ConvNeXt block's hidden tensor
     {
         long L = T;
         int C = c->latent;
         big = std::max(big, (size_t)C * rup((int)L, 4));
         for (size_t i = 0; i < c->ups.size(); i++) {
             L *= c->up_ratio[i];
-            big = std::max(big, (size_t)c->ups[i].pw1.N * rup((int)L, 4));
+            big = std::max(big, (size_t)C * rup((int)L, 4));
+            big2 = std::max(big2, (size_t)c->ups[i].pw1.N * rup((int)L, 4));
         }
         big = std::max(big, (size_t)c->dec_dim * rup((int)L, 4));
         C = c->dec_dim;
@@ -756,10 +787,11 @@ static Plan *get_plan(Ctx *c, int G, int T, bool debug = false) {
             if (c->dual_out >= 2 && !blk_fused(c->blocks[i])) snk_floats = std::max(snk_floats, (size_t)C * rup((int)L, 4) * G);
         }
         big *= G;
+        big2 *= G;
     }
     float *snk_buf = snk_floats ? b.buf(B_SNK, snk_floats) : nullptr;
     if (snk_floats && !snk_buf) return nullptr;
-    float *cur = b.buf(B_BIG0, big), *t1 = b.buf(B_BIG1, big), *t2 = b.buf(B_BIG2, big);
+    float *cur = b.buf(B_BIG0, big), *t1 = b.buf(B_BIG1, big), *t2 = b.buf(B_BIG2, big2);
     if (b.fail || !cur || !t1 || !t2) return nullptr;
     b.gemm("proj", c->out_proj, xn, T, Tp, cur, Tp, nullptr, nullptr, nullptr, ACT_NONE);
     b.mark(st++, cur, c->latent, T, Tp);
@@ -928,8 +960,33 @@ static Plan *get_plan(Ctx *c, int G, int T, bool debug = false) {
         b.mark(st++, nullptr, 1, L, 0);
     }
     if (b.fail) return nullptr;
+    plan->scratch_used = b.soff;
+    return plan;
+}
+
+static Plan *get_plan(Ctx *c, int G, int T, bool debug = false, bool in_scratch = false) {
+    auto key = std::make_pair(debug ? -G : G, T);
+    auto &cache = in_scratch ? c->scratch_plans : c->plans;
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second.get();
+    std::unique_ptr<Plan> plan;
+    if (in_scratch) {
+        // measuring pass first (the base is never dereferenced: nothing is launched), so that a pass that does not fit is
+        // refused with its size in the message
+        size_t need = 0;
+        (void)build_plan(c, G, T, debug, reinterpret_cast<char *>(uintptr_t(1) << 20), ~size_t(0) >> 1, &need);
+        if (need > c->scratch_bytes) {
+            c->err = fmt("%d units of %d frames need %zu MiB of workspace; the static scratch of the allocation-free entry point "
+                         "holds %zu MiB", G, T, (need + (1u << 20) - 1) >> 20, c->scratch_bytes >> 20);
+            return nullptr;
+        }
+        plan = build_plan(c, G, T, debug, static_cast<char *>(c->scratch), c->scratch_bytes, nullptr);
+    } else {
+        plan = build_plan(c, G, T, debug, nullptr, 0, nullptr);
+    }
+    if (!plan) return nullptr;
     Plan *raw = plan.get();
-    c->plans[key] = std::move(plan);
+    cache[key] = std::move(plan);
     return raw;
 }
 
@@ -1100,6 +1157,11 @@ void *hipvoc_load(const char *weights_path, int device_id, int dtype, int unit_f
     if (const char *ps = getenv("HIPVOC_PACKED")) c->packed = atoi(ps) != 0;
     if (const char *ps = getenv("HIPVOC_PHASE_MAJOR")) c->phase_major = atoi(ps) != 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
+    {   // this device's copy of the static scratch array of hipvoc_decode_units_device_noalloc (scratch.hip): resolved
+        // here, once per device, with the device current
+        hipError_t e = scratch_bind(device_id, &c->scratch, &c->scratch_bytes);
+        if (e != hipSuccess) return fail(fmt("hipGetSymbolAddress(scratch) failed on device %d: %s", device_id, hipGetErrorString(e)));
+    }
     std::string err;
     if (!load_model(c.get(), weights_path, err)) return fail(err);
     // size the workspace for a full group now, so later calls never allocate inside the plan
@@ -1133,6 +1195,27 @@ int hipvoc_decode_units_device(void *h, const int64_t *d_codes, int n_units, flo
     if (!d_codes || !d_out || n_units < 0) { c->err = "bad argument"; return HIPVOC_E_ARG; }
     if ((int64_t)unit_stride < c->out_len(c->unit_frames)) { c->err = "unit_stride smaller than unit_samples"; return HIPVOC_E_CAP; }
     return decode_units_device(c, (const long long *)d_codes, n_units, d_out, unit_stride);
+}
+
+// No counterpart in the reference: for callers that cannot allocate (HIP graph capture, tight serving loops).  Same
+// kernels and launch plan as hipvoc_decode_units_device; the workspace is this device's copy of the static scratch array
+// (scratch.hip), cleared at the start of every call.  No hipMalloc / hipFree / event creation on this path.
+int hipvoc_decode_units_device_noalloc(void *h, const int64_t *d_codes, int n_units, float *d_out, size_t unit_stride) {
+    DEC(h);
+    if (!d_codes || !d_out || n_units < 0) { c->err = "bad argument"; return HIPVOC_E_ARG; }
+    if ((int64_t)unit_stride < c->out_len(c->unit_frames)) { c->err = "unit_stride smaller than unit_samples"; return HIPVOC_E_CAP; }
+    if (n_units == 0) return HIPVOC_OK;
+    if (n_units > 128) { c->err = "hipvoc_decode_units_device_noalloc: at most 128 units per call"; return HIPVOC_E_SCRATCH; }
+    if (!c->scratch) { c->err = "static scratch not bound"; return HIPVOC_E_HIP; }
+    Plan *p = get_plan(c, n_units, c->unit_frames, false, true);      // host-side bookkeeping only; refuses what does not fit
+    if (!p) return HIPVOC_E_SCRATCH;
+    // every call on this GPU shares the array and finds the last call's contents in it
+    HIPCHK(hipMemsetAsync(c->scratch, 0, p->scratch_used, c->stream));
+    const bool prof = c->profile;
+    c->profile = false;                                               // profiling creates events
+    int rc = run_plan(c, p, (const long long *)d_codes, d_out, (long)unit_stride, -1, nullptr);
+    c->profile = prof;
+    return rc;
 }
 
 int hipvoc_sync(void *h) {

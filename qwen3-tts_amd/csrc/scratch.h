@@ -1,0 +1,15 @@
+// Static device workspace of the allocation-free entry point (scratch.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+// 256 MiB per GPU: one 10 s utterance (two 64-frame units) of the full-size decoder in fp32 / bf16x3, or one unit in the
+// bf16 mode with its packed exchange tensors; many units of smaller topologies.
+#define HIPVOC_SCRATCH_BYTES (256u << 20)
+#define HIPVOC_SCRATCH_MAX_DEVICES 64
+
+namespace hipvoc {
+// Device address and size of `device`'s copy of the scratch array.  The first call for a device resolves the symbol and
+// must be made with that device current (hipvoc_load does); later calls return the cached pointer.
+hipError_t scratch_bind(int device, void **ptr, size_t *bytes);
+}

@@ -20,7 +20,8 @@ SAMPLE_RATE = 24000             # src/protocol.rs:121
 
 EXPORTS = [
     "hipvoc_device_count", "hipvoc_load", "hipvoc_max_tokens", "hipvoc_unit_samples", "hipvoc_run",
-    "hipvoc_decode", "hipvoc_decode_batch", "hipvoc_vocode_pcm16", "hipvoc_decode_units_device", "hipvoc_sync",
+    "hipvoc_decode", "hipvoc_decode_batch", "hipvoc_vocode_pcm16", "hipvoc_decode_units_device", "hipvoc_decode_units_device_noalloc",
+    "hipvoc_sync",
     "hipvoc_stream", "hipvoc_group_units", "hipvoc_unit_macs", "hipvoc_num_stages", "hipvoc_debug_stage",
     "hipvoc_set_profile", "hipvoc_last_profile", "hipvoc_last_error", "hipvoc_free",
 ]
@@ -60,6 +61,7 @@ def load_library():
     L.hipvoc_decode_batch.argtypes = [vp, i64p, vp, C.c_int, vp, vp, vp]
     L.hipvoc_vocode_pcm16.argtypes = [vp, vp, C.c_int, vp, sz, C.POINTER(sz)]
     L.hipvoc_decode_units_device.argtypes = [vp, vp, C.c_int, vp, sz]
+    L.hipvoc_decode_units_device_noalloc.argtypes = [vp, vp, C.c_int, vp, sz]
     L.hipvoc_sync.argtypes = [vp]
     L.hipvoc_stream.restype = vp
     L.hipvoc_stream.argtypes = [vp]
@@ -179,6 +181,10 @@ class HipVocoder:
 
     def decode_units_device(self, d_codes_ptr: int, n_units: int, d_out_ptr: int, unit_stride: int):
         self._check(self._L.hipvoc_decode_units_device(self._h, d_codes_ptr, n_units, d_out_ptr, unit_stride))
+
+    def decode_units_device_noalloc(self, d_codes_ptr: int, n_units: int, d_out_ptr: int, unit_stride: int):
+        """The entry point that allocates nothing: workspace in the library's static device array (include/hipvoc.h)."""
+        self._check(self._L.hipvoc_decode_units_device_noalloc(self._h, d_codes_ptr, n_units, d_out_ptr, unit_stride))
 
     def sync(self):
         self._check(self._L.hipvoc_sync(self._h))
