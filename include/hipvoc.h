@@ -10,7 +10,14 @@
  *
  * Threading (src/worker/mod.rs:567-577,628-631): calls on one handle are serialised by the
  * caller (the worker holds a tokio Mutex); a handle may be used from different threads over time.
- * The library keeps no thread-local state and sets the HIP device on every call.
+ * The library keeps no thread-local state (but the text of a failed load) and sets the HIP device on every call.
+ *
+ * Host entry points (hipvoc_run / decode / decode_batch / vocode_pcm16*) take and return HOST memory and are complete on
+ * return.  They allocate nothing: pinned staging, device buffers, events and a copy stream for two passes in flight are
+ * created once in hipvoc_load; pass k's samples leave the GPU as one copy while pass k+1 computes.
+ * Device entry points (hipvoc_decode_units_device*) enqueue on the handle's own NON-BLOCKING stream, which has no implicit
+ * ordering with the null stream or the caller's streams: d_codes must be complete on the device before the call, and
+ * d_out is valid (and d_codes reusable) only after hipvoc_sync(h) -- or order against hipvoc_stream(h) with events.
  */
 #ifndef HIPVOC_H
 #define HIPVOC_H
@@ -31,6 +38,8 @@ extern "C" {
 #define HIPVOC_E_HIP (-5)       /* HIP runtime / launch failure (text in hipvoc_last_error) */
 #define HIPVOC_E_MODEL (-6)     /* weights file unreadable / unsupported architecture */
 #define HIPVOC_E_SCRATCH (-7)   /* hipvoc_decode_units_device_noalloc: the pass does not fit the static scratch */
+#define HIPVOC_E_NOMEM (-8)     /* host allocation failed inside the library (caught at the boundary, never thrown across it) */
+#define HIPVOC_E_INTERNAL (-9)  /* any other C++ exception caught at the boundary (text in hipvoc_last_error) */
 
 #define HIPVOC_DTYPE_F32 0
 #define HIPVOC_DTYPE_BF16 1     /* bf16 conv-GEMM mode: operands of every conv / linear / transposed conv rounded to bf16
@@ -61,8 +70,21 @@ int hipvoc_device_count(void);
  */
 void *hipvoc_load(const char *weights_path, int device_id, int dtype, int unit_frames);
 
+/*
+ * Replaces find_vocoder_model (src/worker/mod.rs:792-813): the first existing candidate under models_dir (or its
+ * "vocoder" sub-directory, the role directory download::ensure_models returns, src/download.rs:43-94), in this order:
+ * vocoder.safetensors, vocoder_64.safetensors, vocoder_256.safetensors, model.safetensors,
+ * speech_tokenizer/model.safetensors.  Returns 0 and the path in path_out, or HIPVOC_E_MODEL with the reason in
+ * path_out ("No vocoder model found in <dir> ...", as the reference words it).  Host code only; no GPU needed.
+ */
+int hipvoc_find_vocoder_model(const char *models_dir, char *path_out, size_t cap);
+
 /* `pub max_tokens` of the reference's Vocoder (vocoder.rs:17). */
 int hipvoc_max_tokens(void *h);
+
+/* Codebooks per frame the loaded decoder expects (16 for the shipped model: the `16` of src/worker/vocoder.rs:62,69-72 and
+ * src/worker/mod.rs:513), derived from the weights file. */
+int hipvoc_n_codebooks(void *h);
 
 /* Samples one full unit produces: out_len(unit_frames) = 1920*unit_frames - 555 for the shipped
  * topology (length of OnnxVocoder::run's output). */
@@ -97,6 +119,11 @@ int hipvoc_decode_batch(void *h, const int64_t *codes, const int32_t *n_frames, 
  */
 int hipvoc_vocode_pcm16(void *h, const uint8_t *codes_le, int n_frames, int16_t *pcm, size_t pcm_cap,
                         size_t *n_samples);
+
+/* Batched form of hipvoc_vocode_pcm16 (the VocodeBatch request): codes_le = the B sequences' i64-LE bytes
+ * concatenated; sequence b's PCM goes to pcm + out_off[b] (capacity n_frames[b]*1920 samples), its count to n_samples[b]. */
+int hipvoc_vocode_pcm16_batch(void *h, const uint8_t *codes_le, const int32_t *n_frames, int B, int16_t *pcm,
+                              const size_t *out_off, size_t *n_samples);
 
 /*
  * Device-resident batched units (what bench.py times): d_codes [n_units, max_tokens, 16] i64 and
@@ -152,7 +179,9 @@ int hipvoc_debug_stage(void *h, const int64_t *codes, int n_frames, int stage, f
 int hipvoc_set_profile(void *h, int on);
 int hipvoc_last_profile(void *h, const char **names, float *ms, double *flops, int *launches, int cap);
 
-/* Text of the last error on this handle (or of the last failed hipvoc_load if h is NULL). */
+/* Text of the last error on this handle, or (h == NULL) of the CALLING THREAD's last failed hipvoc_load /
+ * hipvoc_enc_load: per thread, so concurrent loads do not race.  The pointer stays valid until the next failing call
+ * on that handle / that thread's next failed load. */
 const char *hipvoc_last_error(void *h);
 
 void hipvoc_free(void *h);

@@ -451,10 +451,9 @@ extern "C" {
     EncModel *m = enc_of(c);                                                                    \
     if (!m) { c->err = "not an encoder handle"; return HIPVOC_E_ARG; }
 
-void *hipvoc_enc_load(const char *weights_path, int device_id) {
+static void *enc_load_impl(const char *weights_path, int device_id) {
     auto fail = [](const std::string &m) -> void * {
-        std::lock_guard<std::mutex> lk(g_err_mu);
-        g_load_err = m;
+        set_load_error(m.c_str());
         return nullptr;
     };
     if (!weights_path) return fail("weights_path is null");
@@ -473,6 +472,19 @@ void *hipvoc_enc_load(const char *weights_path, int device_id) {
     if (hipDeviceSynchronize() != hipSuccess) return fail("device error after load");
     c->enc = m.release();
     return c.release();
+}
+
+void *hipvoc_enc_load(const char *weights_path, int device_id) {
+    try {
+        return enc_load_impl(weights_path, device_id);
+    } catch (const std::bad_alloc &) {
+        set_load_error("hipvoc_enc_load: out of host memory");
+    } catch (const std::exception &e) {
+        set_load_error(e.what());
+    } catch (...) {
+        set_load_error("hipvoc_enc_load: unknown C++ exception");
+    }
+    return nullptr;
 }
 
 int hipvoc_enc_n_codebooks(void *h) {
@@ -498,24 +510,26 @@ double hipvoc_enc_macs_per_sample(void *h) {
 
 int hipvoc_enc_encode_batch(void *h, const float *const *audio, const int64_t *n_samples, int B, int64_t *const *codes,
                             const size_t *codes_cap, int64_t *n_frames) {
-    ENC(h)
-    if (!audio || !n_samples || !codes || !codes_cap || !n_frames || B < 1) { c->err = "bad argument"; return HIPVOC_E_ARG; }
-    const int nq = m->n_sem + m->n_ac;
-    for (int i = 0; i < B; i++) {
-        if (n_samples[i] < 0) { c->err = "bad argument"; return HIPVOC_E_ARG; }
-        n_frames[i] = m->n_frames(n_samples[i]);
-        if (n_frames[i] < 1) { c->err = fmt("audio %d too short: %lld samples give no frame", i, (long long)n_samples[i]); return HIPVOC_E_ARG; }
-        if ((size_t)n_frames[i] * nq > codes_cap[i]) { c->err = "output capacity too small"; return HIPVOC_E_CAP; }
-    }
-    Plan *p = nullptr;
-    int rc = enc_run(c, m, audio, n_samples, B, -1, nullptr, &p);
-    if (rc) return rc;
-    std::vector<long long> host((size_t)B * p->T * nq);
-    HIPCHK(hipMemcpyAsync(host.data(), m->d_codes, host.size() * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    for (int i = 0; i < B; i++)      // frames past an utterance's own length come from its zero padding: dropped
-        for (size_t j = 0; j < (size_t)n_frames[i] * nq; j++) codes[i][j] = host[(size_t)i * p->T * nq + j];
-    return HIPVOC_OK;
+    return guarded(h, [&]() -> int {
+        ENC(h)
+        if (!audio || !n_samples || !codes || !codes_cap || !n_frames || B < 1) { c->err = "bad argument"; return HIPVOC_E_ARG; }
+        const int nq = m->n_sem + m->n_ac;
+        for (int i = 0; i < B; i++) {
+            if (n_samples[i] < 0) { c->err = "bad argument"; return HIPVOC_E_ARG; }
+            n_frames[i] = m->n_frames(n_samples[i]);
+            if (n_frames[i] < 1) { c->err = fmt("audio %d too short: %lld samples give no frame", i, (long long)n_samples[i]); return HIPVOC_E_ARG; }
+            if ((size_t)n_frames[i] * nq > codes_cap[i]) { c->err = "output capacity too small"; return HIPVOC_E_CAP; }
+        }
+        Plan *p = nullptr;
+        int rc = enc_run(c, m, audio, n_samples, B, -1, nullptr, &p);
+        if (rc) return rc;
+        std::vector<long long> host((size_t)B * p->T * nq);
+        HIPCHK(hipMemcpyAsync(host.data(), m->d_codes, host.size() * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        for (int i = 0; i < B; i++)      // frames past an utterance's own length come from its zero padding: dropped
+            for (size_t j = 0; j < (size_t)n_frames[i] * nq; j++) codes[i][j] = host[(size_t)i * p->T * nq + j];
+        return HIPVOC_OK;
+    });
 }
 
 int hipvoc_enc_encode(void *h, const float *audio, int64_t n_samples, int64_t *codes, size_t codes_cap, int64_t *n_frames) {
@@ -528,11 +542,13 @@ int hipvoc_enc_encode(void *h, const float *audio, int64_t n_samples, int64_t *c
 }
 
 int hipvoc_enc_encode_device(void *h, const float *d_audio, int B, int64_t n_samples, size_t stride, int64_t *d_codes) {
-    ENC(h)
-    if (!d_audio || !d_codes || B < 1 || n_samples < 1 || stride < (size_t)n_samples) { c->err = "bad argument"; return HIPVOC_E_ARG; }
-    std::vector<int64_t> ns((size_t)B, n_samples);
-    std::vector<const float *> none((size_t)B, nullptr);
-    return enc_run(c, m, none.data(), ns.data(), B, -1, nullptr, nullptr, d_audio, stride, (long long *)d_codes);
+    return guarded(h, [&]() -> int {
+        ENC(h)
+        if (!d_audio || !d_codes || B < 1 || n_samples < 1 || stride < (size_t)n_samples) { c->err = "bad argument"; return HIPVOC_E_ARG; }
+        std::vector<int64_t> ns((size_t)B, n_samples);
+        std::vector<const float *> none((size_t)B, nullptr);
+        return enc_run(c, m, none.data(), ns.data(), B, -1, nullptr, nullptr, d_audio, stride, (long long *)d_codes);
+    });
 }
 
 int hipvoc_enc_num_stages(void *h) {
@@ -542,24 +558,26 @@ int hipvoc_enc_num_stages(void *h) {
 }
 
 int hipvoc_enc_debug_stage(void *h, const float *audio, int64_t n_samples, int stage, float *out, size_t out_cap, int *Cc, int64_t *Ll) {
-    ENC(h)
-    const int nst = hipvoc_enc_num_stages(h);
-    if (!audio || !out || stage < 0 || stage >= nst) { c->err = "no such stage"; return HIPVOC_E_STAGE; }
-    const Step *st = nullptr;
-    const int want = stage == nst - 1 ? nst - 2 : stage;       // both projections are produced by the last step
-    const float *ap[1] = {audio};
-    int rc = enc_run(c, m, ap, &n_samples, 1, want, &st, nullptr);
-    if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(c->stream));
-    if (!st) { c->err = "stage not reached"; return HIPVOC_E_STAGE; }
-    const float *src = st->out;
-    int C = st->C, L = st->L, Lp = st->Lp;
-    if (stage == nst - 1) src += (size_t)m->D * Lp;            // acoustic projection follows the semantic one (G = 1)
-    if ((size_t)C * L > out_cap) { c->err = "output capacity too small"; return HIPVOC_E_CAP; }
-    HIPCHK(hipMemcpy2D(out, (size_t)L * sizeof(float), src, (size_t)Lp * sizeof(float), (size_t)L * sizeof(float), C, hipMemcpyDeviceToHost));
-    if (Cc) *Cc = C;
-    if (Ll) *Ll = L;
-    return HIPVOC_OK;
+    return guarded(h, [&]() -> int {
+        ENC(h)
+        const int nst = hipvoc_enc_num_stages(h);
+        if (!audio || !out || stage < 0 || stage >= nst) { c->err = "no such stage"; return HIPVOC_E_STAGE; }
+        const Step *st = nullptr;
+        const int want = stage == nst - 1 ? nst - 2 : stage;       // both projections are produced by the last step
+        const float *ap[1] = {audio};
+        int rc = enc_run(c, m, ap, &n_samples, 1, want, &st, nullptr);
+        if (rc) return rc;
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (!st) { c->err = "stage not reached"; return HIPVOC_E_STAGE; }
+        const float *src = st->out;
+        int C = st->C, L = st->L, Lp = st->Lp;
+        if (stage == nst - 1) src += (size_t)m->D * Lp;            // acoustic projection follows the semantic one (G = 1)
+        if ((size_t)C * L > out_cap) { c->err = "output capacity too small"; return HIPVOC_E_CAP; }
+        HIPCHK(hipMemcpy2D(out, (size_t)L * sizeof(float), src, (size_t)Lp * sizeof(float), (size_t)L * sizeof(float), C, hipMemcpyDeviceToHost));
+        if (Cc) *Cc = C;
+        if (Ll) *Ll = L;
+        return HIPVOC_OK;
+    });
 }
 
 // resample (speech_tokenizer.rs:725-741): linear interpolation in f64, cast to f32.  Host code (the reference does it

@@ -24,14 +24,17 @@
 #include <string>
 #include <vector>
 
+#include "abi_guard.hpp"
+#include "chunking.hpp"
 #include "kernels.h"
 #include "safetensors.hpp"
 #include "scratch.h"
 
 namespace hipvoc {
 
-static std::mutex g_err_mu;
-static std::string g_load_err;
+// text of the calling thread's last failed hipvoc_load / hipvoc_enc_load (hipvoc_last_error(NULL)): per thread, so
+// concurrent loads (hipvoc-worker loads contexts x devices) cannot clobber or race on each other's message
+static thread_local std::string g_load_err;
 
 static std::string fmt(const char *f, ...) {
     char buf[512];
@@ -154,10 +157,20 @@ struct Ctx {
     float *cur_out = nullptr;
     long cur_out_stride = 0;
 
-    // host API staging
+    // staging of the debug-stage entry point (grown on demand; diagnostics only)
     long long *d_codes = nullptr; size_t d_codes_cap = 0;
     float *d_wave = nullptr; size_t d_wave_cap = 0;
-    int16_t *d_pcm = nullptr; size_t d_pcm_cap = 0;
+
+    // host entry points: two-slot pipeline over passes, allocated once at load (alloc_host_pipeline)
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_done[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
+    long long *h_codes[2] = {nullptr, nullptr};        // pinned: the padded codes of one pass
+    long long *d_codes_slot[2] = {nullptr, nullptr};
+    float *d_wave_slot[2] = {nullptr, nullptr};        // [group][slot_stride]
+    int16_t *d_pcm_slot[2] = {nullptr, nullptr};
+    void *h_out[2] = {nullptr, nullptr};               // pinned: one pass of f32 samples (or i16 PCM)
+    std::vector<UnitRef> slot_units[2];
+    size_t slot_stride = 0;
 
     // profile of the last group
     std::vector<std::string> prof_names;
@@ -172,7 +185,16 @@ struct Ctx {
         for (void *p : dev_allocs) (void)hipFree(p);
         if (d_codes) (void)hipFree(d_codes);
         if (d_wave) (void)hipFree(d_wave);
-        if (d_pcm) (void)hipFree(d_pcm);
+        for (int s = 0; s < 2; s++) {
+            if (h_codes[s]) (void)hipHostFree(h_codes[s]);
+            if (h_out[s]) (void)hipHostFree(h_out[s]);
+            if (d_codes_slot[s]) (void)hipFree(d_codes_slot[s]);
+            if (d_wave_slot[s]) (void)hipFree(d_wave_slot[s]);
+            if (d_pcm_slot[s]) (void)hipFree(d_pcm_slot[s]);
+            if (ev_done[s]) (void)hipEventDestroy(ev_done[s]);
+            if (ev_copied[s]) (void)hipEventDestroy(ev_copied[s]);
+        }
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
         if (stream) (void)hipStreamDestroy(stream);
     }
 
@@ -1078,44 +1100,167 @@ static int ensure(Ctx *c, T *&ptr, size_t &cap, size_t need) {
     return HIPVOC_OK;
 }
 
-// Splits sequences into reference units (vocoder.rs:65-72): returns padded codes [U][T][nq] and,
-// per unit, (sequence, kept samples).
-struct UnitMap { int seq; size_t keep; };
+// ---------------------------------------------------------------------------------------------
+// Host entry points: a two-slot pipeline over passes of `group` units.  Everything it needs is allocated ONCE, at load:
+// per slot a pinned code staging buffer, device codes / waveform / PCM buffers of one pass, a pinned output staging buffer
+// and two events; plus a copy stream.  Pass k's kept samples leave the GPU as ONE device-to-host copy on the copy stream
+// (into pinned memory) while pass k+1 computes; the host then scatters them into the caller's (pageable) buffers.  No
+// hipMalloc / hipFree and no host allocation happens in a decode call.
+static bool alloc_host_pipeline(Ctx *c, std::string &err) {
+    const int T = c->unit_frames;
+    const size_t stride = (size_t)rupl(c->out_len(T), 64);
+    const size_t ncodes = (size_t)c->group * T * c->n_q;
+    c->slot_stride = stride;
+    hipError_t e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
+    for (int s = 0; s < 2 && e == hipSuccess; s++) {
+        e = hipEventCreateWithFlags(&c->ev_done[s], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_copied[s], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_codes[s], ncodes * sizeof(long long), hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostMalloc(&c->h_out[s], (size_t)c->group * stride * sizeof(float), hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMalloc((void **)&c->d_codes_slot[s], ncodes * sizeof(long long));
+        if (e == hipSuccess) e = hipMalloc((void **)&c->d_wave_slot[s], (size_t)c->group * stride * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void **)&c->d_pcm_slot[s], (size_t)c->group * stride * sizeof(int16_t));
+        if (e == hipSuccess) c->slot_units[s].reserve((size_t)c->group);
+    }
+    if (e != hipSuccess) {
+        err = std::string("host pipeline allocation failed: ") + hipGetErrorString(e);
+        return false;
+    }
+    return true;
+}
 
-static int build_units(Ctx *c, const int64_t *codes, const int32_t *n_frames, int B, std::vector<long long> &padded,
-                       std::vector<UnitMap> &units) {
-    int T = c->unit_frames, nq = c->n_q;
-    size_t total = 0;
+// Sequences -> reference units (vocoder.rs:65-72) -> passes -> kept samples in the caller's buffers.
+//   out / pcm    : exactly one is non-null (f32 samples, or i16 PCM converted on the GPU)
+//   out_cap      : per-sequence capacity in samples, or null for n_frames[b] * 1920
+//   whole_unit   : hipvoc_run -- the single full unit keeps all unit_samples (OnnxVocoder::run returns the whole graph output)
+// `codes` may be unaligned (the wire hands i64 little-endian bytes): it is only read with memcpy.
+static int decode_host(Ctx *c, const void *codes, const int32_t *n_frames, int B, float *out, int16_t *pcm,
+                       const size_t *out_off, const size_t *out_cap, size_t *n_out, bool whole_unit = false) {
+    static_assert(__BYTE_ORDER__ == __ORDER_LITTLE_ENDIAN__, "i64::from_le_bytes (mod.rs:513-516) is a plain load on this host");
+    const int T = c->unit_frames, nq = c->n_q;
+    const int64_t Lu = c->out_len(T);
+    const size_t stride = c->slot_stride;
+    const size_t esz = pcm ? sizeof(int16_t) : sizeof(float);
+    const unsigned char *cbytes = static_cast<const unsigned char *>(codes);
+    // 1. extents and capacity -- before any device work
+    size_t total_units = 0;
     for (int b = 0; b < B; b++) {
-        if (n_frames[b] < 0) { c->err = "negative n_frames"; return HIPVOC_E_ARG; }
-        total += ((size_t)n_frames[b] + T - 1) / T;
+        size_t smp = 0, nu = 0;
+        if (n_frames[b] < 0 || !sequence_extent(n_frames[b], T, Lu, &smp, &nu)) { c->err = "negative n_frames"; return HIPVOC_E_ARG; }
+        if (whole_unit) smp = (size_t)Lu;
+        const size_t cap = out_cap ? out_cap[b] : (size_t)n_frames[b] * HIPVOC_SAMPLES_PER_TOKEN;
+        if (smp > cap) { c->err = fmt("output capacity too small for sequence %d", b); return HIPVOC_E_CAP; }
+        total_units += nu;
+        n_out[b] = 0;
     }
-    padded.assign(total * T * nq, 0);      // pad = code index 0 (vocoder.rs:62,70)
-    units.clear();
-    units.reserve(total);
-    int64_t Lu = c->out_len(T);
-    size_t src = 0, ui = 0;
-    for (int b = 0; b < B; b++) {
-        for (int start = 0; start < n_frames[b]; start += T) {
-            int len = std::min(T, n_frames[b] - start);
-            for (size_t i = 0; i < (size_t)len * nq; i++) {
-                long long v = codes[(src + start) * nq + i];
-                if (v < 0 || v >= c->cb_size) {
-                    c->err = fmt("code %lld outside [0,%d) in sequence %d frame %d", v, c->cb_size, b, start + (int)(i / nq));
-                    return HIPVOC_E_CODE;
-                }
-                padded[ui * T * nq + i] = v;
+    // 2. every code in [0, codebook_size) -- the request is refused whole, nothing is decoded
+    {
+        size_t frame0 = 0;
+        for (int b = 0; b < B; b++) {
+            const size_t n = (size_t)n_frames[b] * nq;
+            int64_t v = 0;
+            const size_t bad = first_bad_code(cbytes + frame0 * nq * sizeof(int64_t), n, c->cb_size, &v);
+            if (bad < n) {
+                c->err = fmt("code %lld outside [0,%d) in sequence %d frame %zu", (long long)v, c->cb_size, b, bad / nq);
+                return HIPVOC_E_CODE;
             }
-            size_t keep = std::min<size_t>((size_t)len * HIPVOC_SAMPLES_PER_TOKEN, (size_t)Lu);   // vocoder.rs:79-80
-            units.push_back({b, keep});
-            ui++;
+            frame0 += (size_t)n_frames[b];
         }
-        src += n_frames[b];
     }
-    return HIPVOC_OK;
+    if (total_units == 0) return HIPVOC_OK;
+    // 3. passes
+    auto drain = [&](int s) -> int {
+        HIPCHK(hipEventSynchronize(c->ev_copied[s]));
+        const unsigned char *src = static_cast<const unsigned char *>(c->h_out[s]);
+        unsigned char *dst = pcm ? reinterpret_cast<unsigned char *>(pcm) : reinterpret_cast<unsigned char *>(out);
+        const std::vector<UnitRef> &us = c->slot_units[s];
+        for (size_t i = 0; i < us.size(); i++) {
+            memcpy(dst + us[i].dst * esz, src + i * stride * esz, us[i].keep * esz);
+            n_out[us[i].seq] += us[i].keep;
+        }
+        return HIPVOC_OK;
+    };
+    UnitWalker walk(n_frames, B, T, Lu, out_off);
+    int cur_seq = 0, pending = -1;
+    size_t seq_frame0 = 0;                 // first frame of sequence cur_seq in `codes`
+    for (int k = 0;; k++) {
+        const int s = k & 1;
+        std::vector<UnitRef> &us = c->slot_units[s];
+        us.clear();
+        UnitRef u;
+        while ((int)us.size() < c->group && walk.next(u)) {
+            if (whole_unit) u.keep = (size_t)Lu;
+            us.push_back(u);                // (capacity reserved at load: no allocation)
+        }
+        if (us.empty()) break;
+        const int G = (int)us.size();
+        const size_t unit_codes = (size_t)T * nq;
+        memset(c->h_codes[s], 0, (size_t)G * unit_codes * sizeof(long long));      // pad = code index 0 (vocoder.rs:62,70)
+        for (int i = 0; i < G; i++) {
+            while (cur_seq < us[i].seq) seq_frame0 += (size_t)n_frames[cur_seq++];
+            memcpy(c->h_codes[s] + (size_t)i * unit_codes, cbytes + (seq_frame0 + (size_t)us[i].start) * nq * sizeof(int64_t),
+                   (size_t)us[i].len * nq * sizeof(int64_t));
+        }
+        HIPCHK(hipMemcpyAsync(c->d_codes_slot[s], c->h_codes[s], (size_t)G * unit_codes * sizeof(long long), hipMemcpyHostToDevice, c->stream));
+        Plan *p = get_plan(c, G, T);
+        if (!p) return HIPVOC_E_HIP;
+        int rc = run_plan(c, p, c->d_codes_slot[s], c->d_wave_slot[s], (long)stride, -1, nullptr);
+        if (rc) return rc;
+        const size_t n_el = (size_t)(G - 1) * stride + us.back().keep;              // one contiguous copy per pass
+        const void *d_src = c->d_wave_slot[s];
+        if (pcm) {
+            hipError_t e = launch_pcm16(c->d_wave_slot[s], c->d_pcm_slot[s], (long)n_el, c->stream);
+            if (e != hipSuccess) { c->err = std::string("pcm16 launch: ") + hipGetErrorString(e); return HIPVOC_E_HIP; }
+            d_src = c->d_pcm_slot[s];
+        }
+        HIPCHK(hipEventRecord(c->ev_done[s], c->stream));
+        HIPCHK(hipStreamWaitEvent(c->copy_stream, c->ev_done[s], 0));
+        HIPCHK(hipMemcpyAsync(c->h_out[s], d_src, n_el * esz, hipMemcpyDeviceToHost, c->copy_stream));
+        HIPCHK(hipEventRecord(c->ev_copied[s], c->copy_stream));
+        if (pending >= 0) {                  // the previous pass's samples, while this one computes
+            rc = drain(pending);
+            if (rc) return rc;
+        }
+        pending = s;
+    }
+    if (pending >= 0) {
+        int rc = drain(pending);
+        if (rc) return rc;
+    }
+    return sync_check(c);
+}
+
+// decode_host, leaving both streams idle whatever happened (the slots are reused by the next call)
+static int decode_host_safe(Ctx *c, const void *codes, const int32_t *n_frames, int B, float *out, int16_t *pcm,
+                            const size_t *out_off, const size_t *out_cap, size_t *n_out, bool whole_unit = false) {
+    int rc = decode_host(c, codes, n_frames, B, out, pcm, out_off, out_cap, n_out, whole_unit);
+    if (rc) {
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipStreamSynchronize(c->copy_stream);
+    }
+    return rc;
 }
 
 static void enc_release(Ctx *c);      // encoder.inc.cpp
+
+// last failed hipvoc_load / hipvoc_enc_load (no handle to hang the text on)
+static void set_load_error(const char *m) noexcept {
+    try {
+        g_load_err = m;
+    } catch (...) {
+    }
+}
+
+// exception barrier for entry points that have a handle: the text goes to the handle
+template <typename Body>
+static inline int guarded(void *h, Body &&body) noexcept {
+    return abi_guard(body, [h](const char *what) noexcept {
+        try {
+            if (h) static_cast<Ctx *>(h)->err = what;
+        } catch (...) {
+        }
+    });
+}
 
 }  // namespace hipvoc
 
@@ -1130,10 +1275,9 @@ int hipvoc_device_count(void) {
     return n;
 }
 
-void *hipvoc_load(const char *weights_path, int device_id, int dtype, int unit_frames) {
+static void *load_impl(const char *weights_path, int device_id, int dtype, int unit_frames) {
     auto fail = [](const std::string &m) -> void * {
-        std::lock_guard<std::mutex> lk(g_err_mu);
-        g_load_err = m;
+        set_load_error(m.c_str());
         return nullptr;
     };
     if (!weights_path) return fail("weights_path is NULL");
@@ -1171,8 +1315,22 @@ void *hipvoc_load(const char *weights_path, int device_id, int dtype, int unit_f
     double macs = 0;
     for (auto &s : p->steps) macs += s.macs;
     c->unit_macs = (int64_t)(macs / c->group);
+    if (!alloc_host_pipeline(c.get(), err)) return fail(err);
     if (hipDeviceSynchronize() != hipSuccess) return fail("device error after load");
     return c.release();
+}
+
+void *hipvoc_load(const char *weights_path, int device_id, int dtype, int unit_frames) {
+    try {
+        return load_impl(weights_path, device_id, dtype, unit_frames);
+    } catch (const std::bad_alloc &) {
+        set_load_error("hipvoc_load: out of host memory");
+    } catch (const std::exception &e) {
+        set_load_error(e.what());
+    } catch (...) {
+        set_load_error("hipvoc_load: unknown C++ exception");
+    }
+    return nullptr;
 }
 
 #define CTX(h)                    \
@@ -1185,154 +1343,110 @@ void *hipvoc_load(const char *weights_path, int device_id, int dtype, int unit_f
     if (c->is_encoder) { c->err = "this handle is an encoder (hipvoc_enc_load)"; return HIPVOC_E_ARG; }
 
 int hipvoc_max_tokens(void *h) { return h ? ((Ctx *)h)->unit_frames : HIPVOC_E_ARG; }
+int hipvoc_n_codebooks(void *h) { return h ? ((Ctx *)h)->n_q : HIPVOC_E_ARG; }
 int64_t hipvoc_unit_samples(void *h) { return h ? ((Ctx *)h)->out_len(((Ctx *)h)->unit_frames) : HIPVOC_E_ARG; }
 int hipvoc_group_units(void *h) { return h ? ((Ctx *)h)->group : HIPVOC_E_ARG; }
 int64_t hipvoc_unit_macs(void *h) { return h ? ((Ctx *)h)->unit_macs : HIPVOC_E_ARG; }
 void *hipvoc_stream(void *h) { return h ? (void *)((Ctx *)h)->stream : nullptr; }
 
 int hipvoc_decode_units_device(void *h, const int64_t *d_codes, int n_units, float *d_out, size_t unit_stride) {
-    DEC(h);
-    if (!d_codes || !d_out || n_units < 0) { c->err = "bad argument"; return HIPVOC_E_ARG; }
-    if ((int64_t)unit_stride < c->out_len(c->unit_frames)) { c->err = "unit_stride smaller than unit_samples"; return HIPVOC_E_CAP; }
-    return decode_units_device(c, (const long long *)d_codes, n_units, d_out, unit_stride);
+    return guarded(h, [&]() -> int {
+        DEC(h);
+        if (!d_codes || !d_out || n_units < 0) { c->err = "bad argument"; return HIPVOC_E_ARG; }
+        if ((int64_t)unit_stride < c->out_len(c->unit_frames)) { c->err = "unit_stride smaller than unit_samples"; return HIPVOC_E_CAP; }
+        return decode_units_device(c, (const long long *)d_codes, n_units, d_out, unit_stride);
+    });
 }
 
 // No counterpart in the reference: for callers that cannot allocate (HIP graph capture, tight serving loops).  Same
 // kernels and launch plan as hipvoc_decode_units_device; the workspace is this device's copy of the static scratch array
 // (scratch.hip), cleared at the start of every call.  No hipMalloc / hipFree / event creation on this path.
 int hipvoc_decode_units_device_noalloc(void *h, const int64_t *d_codes, int n_units, float *d_out, size_t unit_stride) {
-    DEC(h);
-    if (!d_codes || !d_out || n_units < 0) { c->err = "bad argument"; return HIPVOC_E_ARG; }
-    if ((int64_t)unit_stride < c->out_len(c->unit_frames)) { c->err = "unit_stride smaller than unit_samples"; return HIPVOC_E_CAP; }
-    if (n_units == 0) return HIPVOC_OK;
-    if (n_units > 128) { c->err = "hipvoc_decode_units_device_noalloc: at most 128 units per call"; return HIPVOC_E_SCRATCH; }
-    if (!c->scratch) { c->err = "static scratch not bound"; return HIPVOC_E_HIP; }
-    Plan *p = get_plan(c, n_units, c->unit_frames, false, true);      // host-side bookkeeping only; refuses what does not fit
-    if (!p) return HIPVOC_E_SCRATCH;
-    // every call on this GPU shares the array and finds the last call's contents in it
-    HIPCHK(hipMemsetAsync(c->scratch, 0, p->scratch_used, c->stream));
-    const bool prof = c->profile;
-    c->profile = false;                                               // profiling creates events
-    int rc = run_plan(c, p, (const long long *)d_codes, d_out, (long)unit_stride, -1, nullptr);
-    c->profile = prof;
-    return rc;
+    return guarded(h, [&]() -> int {
+        DEC(h);
+        if (!d_codes || !d_out || n_units < 0) { c->err = "bad argument"; return HIPVOC_E_ARG; }
+        if ((int64_t)unit_stride < c->out_len(c->unit_frames)) { c->err = "unit_stride smaller than unit_samples"; return HIPVOC_E_CAP; }
+        if (n_units == 0) return HIPVOC_OK;
+        if (n_units > 128) { c->err = "hipvoc_decode_units_device_noalloc: at most 128 units per call"; return HIPVOC_E_SCRATCH; }
+        if (!c->scratch) { c->err = "static scratch not bound"; return HIPVOC_E_HIP; }
+        Plan *p = get_plan(c, n_units, c->unit_frames, false, true);      // host-side bookkeeping only; refuses what does not fit
+        if (!p) return HIPVOC_E_SCRATCH;
+        // every call on this GPU shares the array and finds the last call's contents in it
+        HIPCHK(hipMemsetAsync(c->scratch, 0, p->scratch_used, c->stream));
+        const bool prof = c->profile;
+        c->profile = false;                                               // profiling creates events
+        int rc = run_plan(c, p, (const long long *)d_codes, d_out, (long)unit_stride, -1, nullptr);
+        c->profile = prof;
+        return rc;
+    });
 }
 
 int hipvoc_sync(void *h) {
-    CTX(h)
-    if (c->is_encoder) {
-        HIPCHK(hipStreamSynchronize(c->stream));
-        return HIPVOC_OK;
-    }
-    return sync_check(c);
-}
-
-// shared host path: sequences -> units -> device decode -> (optional pcm) -> gather kept samples
-static int decode_host(Ctx *c, const int64_t *codes, const int32_t *n_frames, int B, float *out, int16_t *pcm,
-                       const size_t *out_off, const size_t *out_cap, size_t *n_out) {
-    std::vector<long long> padded;
-    std::vector<UnitMap> units;
-    int rc = build_units(c, codes, n_frames, B, padded, units);
-    if (rc) return rc;
-    // capacity check before any device work
-    {
-        std::vector<size_t> need(B, 0);
-        for (auto &u : units) need[u.seq] += u.keep;
-        for (int b = 0; b < B; b++)
-            if (need[b] > out_cap[b]) { c->err = fmt("output capacity too small for sequence %d", b); return HIPVOC_E_CAP; }
-    }
-    size_t U = units.size();
-    for (int b = 0; b < B; b++) n_out[b] = 0;
-    if (U == 0) return HIPVOC_OK;
-    int64_t Lu = c->out_len(c->unit_frames);
-    size_t stride = (size_t)rupl(Lu, 64);
-    rc = ensure(c, c->d_codes, c->d_codes_cap, padded.size());
-    if (rc) return rc;
-    rc = ensure(c, c->d_wave, c->d_wave_cap, U * stride);
-    if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(c->d_codes, padded.data(), padded.size() * sizeof(long long), hipMemcpyHostToDevice, c->stream));
-    rc = decode_units_device(c, c->d_codes, (int)U, c->d_wave, stride);
-    if (rc) return rc;
-    if (pcm) {
-        rc = ensure(c, c->d_pcm, c->d_pcm_cap, U * stride);
-        if (rc) return rc;
-        hipError_t e = launch_pcm16(c->d_wave, c->d_pcm, (long)(U * stride), c->stream);
-        if (e != hipSuccess) { c->err = std::string("pcm16 launch: ") + hipGetErrorString(e); return HIPVOC_E_HIP; }
-    }
-    std::vector<size_t> pos(B, 0);
-    for (size_t u = 0; u < U; u++) {
-        int b = units[u].seq;
-        if (pcm)
-            HIPCHK(hipMemcpyAsync(pcm + out_off[b] + pos[b], c->d_pcm + u * stride, units[u].keep * sizeof(int16_t), hipMemcpyDeviceToHost, c->stream));
-        else
-            HIPCHK(hipMemcpyAsync(out + out_off[b] + pos[b], c->d_wave + u * stride, units[u].keep * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-        pos[b] += units[u].keep;
-    }
-    rc = sync_check(c);
-    if (rc) return rc;
-    for (int b = 0; b < B; b++) n_out[b] = pos[b];
-    return HIPVOC_OK;
+    return guarded(h, [&]() -> int {
+        CTX(h)
+        if (c->is_encoder) {
+            HIPCHK(hipStreamSynchronize(c->stream));
+            return HIPVOC_OK;
+        }
+        return sync_check(c);
+    });
 }
 
 int hipvoc_run(void *h, const int64_t *codes, int max_tokens, float *out, size_t out_cap, size_t *n_out) {
-    DEC(h);
-    if (!codes || !out) { c->err = "null pointer"; return HIPVOC_E_ARG; }
-    if (max_tokens != c->unit_frames) { c->err = "hipvoc_run: max_tokens must equal the handle's unit_frames"; return HIPVOC_E_ARG; }
-    int64_t Lu = c->out_len(c->unit_frames);
-    if (out_cap < (size_t)Lu) { c->err = "output capacity too small"; return HIPVOC_E_CAP; }
-    // a full unit, but keep ALL Lu samples (OnnxVocoder::run returns the whole graph output)
-    std::vector<long long> padded(codes, codes + (size_t)max_tokens * c->n_q);
-    for (long long v : padded)
-        if (v < 0 || v >= c->cb_size) { c->err = "code index outside [0, codebook_size)"; return HIPVOC_E_CODE; }
-    size_t stride = (size_t)rupl(Lu, 64);
-    int rc = ensure(c, c->d_codes, c->d_codes_cap, padded.size());
-    if (rc) return rc;
-    rc = ensure(c, c->d_wave, c->d_wave_cap, stride);
-    if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(c->d_codes, padded.data(), padded.size() * sizeof(long long), hipMemcpyHostToDevice, c->stream));
-    rc = decode_units_device(c, c->d_codes, 1, c->d_wave, stride);
-    if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(out, c->d_wave, (size_t)Lu * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    rc = sync_check(c);
-    if (rc) return rc;
-    if (n_out) *n_out = (size_t)Lu;
-    return HIPVOC_OK;
+    return guarded(h, [&]() -> int {
+        DEC(h);
+        if (!codes || !out) { c->err = "null pointer"; return HIPVOC_E_ARG; }
+        if (max_tokens != c->unit_frames) { c->err = "hipvoc_run: max_tokens must equal the handle's unit_frames"; return HIPVOC_E_ARG; }
+        // a full unit, but keep ALL unit_samples (OnnxVocoder::run returns the whole graph output)
+        int32_t nf = max_tokens;
+        size_t off = 0, n = 0;
+        int rc = decode_host_safe(c, codes, &nf, 1, out, nullptr, &off, &out_cap, &n, true);
+        if (!rc && n_out) *n_out = n;
+        return rc;
+    });
 }
 
 int hipvoc_decode(void *h, const int64_t *codes, int n_frames, float *out, size_t out_cap, size_t *n_out) {
-    DEC(h);
-    if ((!codes && n_frames > 0) || (!out && n_frames > 0) || n_frames < 0) { c->err = "bad argument"; return HIPVOC_E_ARG; }
-    int32_t nf = n_frames;
-    size_t off = 0, n = 0;
-    int rc = decode_host(c, codes, &nf, 1, out, nullptr, &off, &out_cap, &n);
-    if (!rc && n_out) *n_out = n;
-    return rc;
+    return guarded(h, [&]() -> int {
+        DEC(h);
+        if ((!codes && n_frames > 0) || (!out && n_frames > 0) || n_frames < 0) { c->err = "bad argument"; return HIPVOC_E_ARG; }
+        int32_t nf = n_frames;
+        size_t off = 0, n = 0;
+        int rc = decode_host_safe(c, codes, &nf, 1, out, nullptr, &off, &out_cap, &n);
+        if (!rc && n_out) *n_out = n;
+        return rc;
+    });
 }
 
 int hipvoc_decode_batch(void *h, const int64_t *codes, const int32_t *n_frames, int B, float *out, const size_t *out_off,
                         size_t *n_out) {
-    DEC(h);
-    if (B < 0 || (B > 0 && (!codes || !n_frames || !out || !out_off || !n_out))) { c->err = "bad argument"; return HIPVOC_E_ARG; }
-    std::vector<size_t> cap(B);
-    for (int b = 0; b < B; b++) cap[b] = (size_t)std::max(n_frames[b], 0) * HIPVOC_SAMPLES_PER_TOKEN;
-    return decode_host(c, codes, n_frames, B, out, nullptr, out_off, cap.data(), n_out);
+    return guarded(h, [&]() -> int {
+        DEC(h);
+        if (B < 0 || (B > 0 && (!codes || !n_frames || !out || !out_off || !n_out))) { c->err = "bad argument"; return HIPVOC_E_ARG; }
+        return decode_host_safe(c, codes, n_frames, B, out, nullptr, out_off, nullptr, n_out);
+    });
 }
 
 int hipvoc_vocode_pcm16(void *h, const uint8_t *codes_le, int n_frames, int16_t *pcm, size_t pcm_cap, size_t *n_samples) {
-    DEC(h);
-    if (n_frames < 0 || (n_frames > 0 && (!codes_le || !pcm))) { c->err = "bad argument"; return HIPVOC_E_ARG; }
-    size_t n = (size_t)n_frames * c->n_q;
-    std::vector<int64_t> codes(n);
-    for (size_t i = 0; i < n; i++) {     // i64::from_le_bytes (mod.rs:513-516)
-        uint64_t v = 0;
-        for (int b = 0; b < 8; b++) v |= (uint64_t)codes_le[i * 8 + b] << (8 * b);
-        codes[i] = (int64_t)v;
-    }
-    int32_t nf = n_frames;
-    size_t off = 0, got = 0;
-    int rc = decode_host(c, codes.data(), &nf, 1, nullptr, pcm, &off, &pcm_cap, &got);
-    if (!rc && n_samples) *n_samples = got;
-    return rc;
+    return guarded(h, [&]() -> int {
+        DEC(h);
+        if (n_frames < 0 || (n_frames > 0 && (!codes_le || !pcm))) { c->err = "bad argument"; return HIPVOC_E_ARG; }
+        // i64::from_le_bytes (mod.rs:513-516): the bytes are read in place (little-endian host, memcpy loads)
+        int32_t nf = n_frames;
+        size_t off = 0, got = 0;
+        int rc = decode_host_safe(c, codes_le, &nf, 1, nullptr, pcm, &off, &pcm_cap, &got);
+        if (!rc && n_samples) *n_samples = got;
+        return rc;
+    });
+}
+
+int hipvoc_vocode_pcm16_batch(void *h, const uint8_t *codes_le, const int32_t *n_frames, int B, int16_t *pcm,
+                              const size_t *out_off, size_t *n_samples) {
+    return guarded(h, [&]() -> int {
+        DEC(h);
+        if (B < 0 || (B > 0 && (!codes_le || !n_frames || !pcm || !out_off || !n_samples))) { c->err = "bad argument"; return HIPVOC_E_ARG; }
+        return decode_host_safe(c, codes_le, n_frames, B, nullptr, pcm, out_off, nullptr, n_samples);
+    });
 }
 
 int hipvoc_num_stages(void *h) {
@@ -1342,38 +1456,40 @@ int hipvoc_num_stages(void *h) {
 }
 
 int hipvoc_debug_stage(void *h, const int64_t *codes, int n_frames, int stage, float *out, size_t out_cap, int *Cc, int64_t *Ll) {
-    DEC(h);
-    if (!codes || !out || n_frames < 1 || n_frames > c->unit_frames) { c->err = "bad argument"; return HIPVOC_E_ARG; }
-    int nst = hipvoc_num_stages(h);
-    if (!((stage >= 0 && stage < nst) || stage == 1000)) { c->err = "no such stage"; return HIPVOC_E_STAGE; }
-    std::vector<long long> cv(codes, codes + (size_t)n_frames * c->n_q);
-    for (long long v : cv)
-        if (v < 0 || v >= c->cb_size) { c->err = "code index outside [0, codebook_size)"; return HIPVOC_E_CODE; }
-    Plan *p = get_plan(c, 1, n_frames, true);
-    if (!p) return HIPVOC_E_HIP;
-    int64_t Lu = c->out_len(n_frames);
-    size_t stride = (size_t)rupl(std::max<int64_t>(Lu, 1), 64);
-    int rc = ensure(c, c->d_codes, c->d_codes_cap, cv.size());
-    if (rc) return rc;
-    rc = ensure(c, c->d_wave, c->d_wave_cap, stride);
-    if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(c->d_codes, cv.data(), cv.size() * sizeof(long long), hipMemcpyHostToDevice, c->stream));
-    const Step *st = nullptr;
-    int want = stage == 1000 ? 0 : stage;
-    rc = run_plan(c, p, c->d_codes, c->d_wave, (long)stride, want, &st);
-    if (rc) return rc;
-    rc = sync_check(c);
-    if (rc) return rc;
-    if (!st) { c->err = "stage not reached"; return HIPVOC_E_STAGE; }
-    const float *src = st->out;
-    int C = st->C, L = st->L, Lp = st->Lp;
-    if (stage == 1000) { src = c->bufs[B_SUMS].first; C = 2 * c->cb_dim; }
-    if (!src) { src = c->d_wave; Lp = (int)stride; }      // final stage lives in the output buffer
-    if ((size_t)C * L > out_cap) { c->err = "output capacity too small"; return HIPVOC_E_CAP; }
-    HIPCHK(hipMemcpy2D(out, (size_t)L * sizeof(float), src, (size_t)Lp * sizeof(float), (size_t)L * sizeof(float), C, hipMemcpyDeviceToHost));
-    if (Cc) *Cc = C;
-    if (Ll) *Ll = L;
-    return HIPVOC_OK;
+    return guarded(h, [&]() -> int {
+        DEC(h);
+        if (!codes || !out || n_frames < 1 || n_frames > c->unit_frames) { c->err = "bad argument"; return HIPVOC_E_ARG; }
+        int nst = hipvoc_num_stages(h);
+        if (!((stage >= 0 && stage < nst) || stage == 1000)) { c->err = "no such stage"; return HIPVOC_E_STAGE; }
+        std::vector<long long> cv(codes, codes + (size_t)n_frames * c->n_q);
+        for (long long v : cv)
+            if (v < 0 || v >= c->cb_size) { c->err = "code index outside [0, codebook_size)"; return HIPVOC_E_CODE; }
+        Plan *p = get_plan(c, 1, n_frames, true);
+        if (!p) return HIPVOC_E_HIP;
+        int64_t Lu = c->out_len(n_frames);
+        size_t stride = (size_t)rupl(std::max<int64_t>(Lu, 1), 64);
+        int rc = ensure(c, c->d_codes, c->d_codes_cap, cv.size());
+        if (rc) return rc;
+        rc = ensure(c, c->d_wave, c->d_wave_cap, stride);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(c->d_codes, cv.data(), cv.size() * sizeof(long long), hipMemcpyHostToDevice, c->stream));
+        const Step *st = nullptr;
+        int want = stage == 1000 ? 0 : stage;
+        rc = run_plan(c, p, c->d_codes, c->d_wave, (long)stride, want, &st);
+        if (rc) return rc;
+        rc = sync_check(c);
+        if (rc) return rc;
+        if (!st) { c->err = "stage not reached"; return HIPVOC_E_STAGE; }
+        const float *src = st->out;
+        int C = st->C, L = st->L, Lp = st->Lp;
+        if (stage == 1000) { src = c->bufs[B_SUMS].first; C = 2 * c->cb_dim; }
+        if (!src) { src = c->d_wave; Lp = (int)stride; }      // final stage lives in the output buffer
+        if ((size_t)C * L > out_cap) { c->err = "output capacity too small"; return HIPVOC_E_CAP; }
+        HIPCHK(hipMemcpy2D(out, (size_t)L * sizeof(float), src, (size_t)Lp * sizeof(float), (size_t)L * sizeof(float), C, hipMemcpyDeviceToHost));
+        if (Cc) *Cc = C;
+        if (Ll) *Ll = L;
+        return HIPVOC_OK;
+    });
 }
 
 int hipvoc_set_profile(void *h, int on) {
@@ -1398,10 +1514,9 @@ int hipvoc_last_profile(void *h, const char **names, float *ms, double *flops, i
 
 const char *hipvoc_last_error(void *h) {
     if (!h) {
-        std::lock_guard<std::mutex> lk(g_err_mu);
-        static std::string copy;
-        copy = g_load_err;
-        return copy.c_str();
+        // the calling thread's own last load failure: valid until this thread's next failed load, whatever other
+        // threads load or fail meanwhile
+        return g_load_err.c_str();
     }
     return ((Ctx *)h)->err.c_str();
 }

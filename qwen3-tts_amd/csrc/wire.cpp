@@ -90,6 +90,39 @@ static bool rd_bytes(Rd &r, std::vector<uint8_t> &out) {
     }
     return true;
 }
+// the same into a caller's buffer, without any allocation: out == null counts only; bytes beyond cap are counted, not
+// written (overflow = true)
+static bool rd_bytes_to(Rd &r, uint8_t *out, size_t cap, size_t &n_out, bool &overflow) {
+    uint8_t b = r.peek();
+    size_t len;
+    n_out = 0;
+    if (b == 0xc4 || b == 0xc5 || b == 0xc6) {
+        r.i++;
+        len = (size_t)r.be(b == 0xc4 ? 1 : b == 0xc5 ? 2 : 4);
+        if (r.bad || !r.need(len)) return false;
+        if (out) {
+            if (len > cap) overflow = true;
+            else if (len) memcpy(out, r.p + r.i, len);
+        }
+        r.i += len;
+        n_out = len;
+        return true;
+    }
+    if (!rd_array(r, len)) return false;
+    if (len > r.n - r.i) return false;          // every element takes at least one byte
+    const bool wr = out && len <= cap;
+    if (out && len > cap) overflow = true;
+    for (size_t k = 0; k < len; k++) {
+        if (r.i >= r.n) return false;
+        uint8_t e = r.p[r.i];
+        if (e < 0x80) { if (wr) out[k] = e; r.i++; continue; }       // the common case
+        uint64_t v;
+        if (!rd_uint(r, v) || v > 255) return false;
+        if (wr) out[k] = (uint8_t)v;
+    }
+    n_out = len;
+    return true;
+}
 // skip any object (bounded depth)
 static bool skip(Rd &r, int depth = 0) {
     if (depth > 32) return false;
@@ -219,7 +252,9 @@ struct Wr {
 
 extern "C" {
 
-int hipvoc_wire_parse_request(const uint8_t *msg, size_t len, uint8_t *codes_out, size_t codes_cap, size_t *codes_len,
+// The parsers allocate nothing proportional to the message (a hostile length prefix cannot make them reserve memory:
+// code bytes go straight into the caller's buffer) and let no C++ exception out (variant names are short std::strings).
+static int parse_request_impl(const uint8_t *msg, size_t len, uint8_t *codes_out, size_t codes_cap, size_t *codes_len,
                               uint64_t *n_tokens) {
     if (!msg) return HIPVOC_WIRE_E_MALFORMED;
     Rd r{msg, len};
@@ -234,16 +269,14 @@ int hipvoc_wire_parse_request(const uint8_t *msg, size_t len, uint8_t *codes_out
     if (!payload) return HIPVOC_WIRE_E_MALFORMED;
     if (name == "Vocode") {
         static const char *const f[] = {"codes", "n_tokens"};
-        std::vector<uint8_t> codes;
+        size_t clen = 0;
         uint64_t nt = 0;
-        bool ok = rd_fields(r, f, 2, [&](size_t k) { return k == 0 ? rd_bytes(r, codes) : rd_uint(r, nt); });
+        bool overflow = false;
+        bool ok = rd_fields(r, f, 2, [&](size_t k) { return k == 0 ? rd_bytes_to(r, codes_out, codes_cap, clen, overflow) : rd_uint(r, nt); });
         if (!ok || r.bad || r.i != len) return HIPVOC_WIRE_E_MALFORMED;
-        if (codes_len) *codes_len = codes.size();
+        if (codes_len) *codes_len = clen;
         if (n_tokens) *n_tokens = nt;
-        if (codes_out) {
-            if (codes.size() > codes_cap) return HIPVOC_WIRE_E_CAP;
-            if (!codes.empty()) memcpy(codes_out, codes.data(), codes.size());
-        }
+        if (overflow) return HIPVOC_WIRE_E_CAP;
         return HIPVOC_WIRE_VOCODE;
     }
     if (!skip(r) || r.i != len) return HIPVOC_WIRE_E_MALFORMED;
@@ -252,7 +285,16 @@ int hipvoc_wire_parse_request(const uint8_t *msg, size_t len, uint8_t *codes_out
     return HIPVOC_WIRE_OTHER;
 }
 
-int hipvoc_wire_parse_vocode_batch(const uint8_t *msg, size_t len, uint8_t *codes_out, size_t codes_cap,
+int hipvoc_wire_parse_request(const uint8_t *msg, size_t len, uint8_t *codes_out, size_t codes_cap, size_t *codes_len,
+                              uint64_t *n_tokens) {
+    try {
+        return parse_request_impl(msg, len, codes_out, codes_cap, codes_len, n_tokens);
+    } catch (...) {
+        return HIPVOC_WIRE_E_MALFORMED;
+    }
+}
+
+static int parse_vocode_batch_impl(const uint8_t *msg, size_t len, uint8_t *codes_out, size_t codes_cap,
                                    size_t *offsets, uint64_t *n_tokens, size_t max_items, size_t *n_items) {
     if (!msg || !n_items) return HIPVOC_WIRE_E_MALFORMED;
     Rd r{msg, len};
@@ -260,36 +302,49 @@ int hipvoc_wire_parse_vocode_batch(const uint8_t *msg, size_t len, uint8_t *code
     bool payload;
     if (!rd_variant(r, name, payload) || !payload || name != "VocodeBatch") return HIPVOC_WIRE_E_MALFORMED;
     static const char *const f[] = {"codes", "n_tokens"};
-    std::vector<std::vector<uint8_t>> codes;
-    std::vector<uint64_t> nts;
+    const bool query = !offsets && !codes_out && !n_tokens;         // size query: count the items only
+    size_t n_codes = 0, n_nts = 0, off = 0;
+    bool overflow = false, too_many = false;
     bool ok = rd_fields(r, f, 2, [&](size_t k) {
         size_t cnt;
         if (!rd_array(r, cnt) || cnt > r.n - r.i) return false;
+        if (!query && cnt > max_items) too_many = true;             // keep parsing (validation), write nothing more
         if (k == 0) {
-            codes.resize(cnt);
-            for (size_t j = 0; j < cnt; j++) if (!rd_bytes(r, codes[j])) return false;
+            n_codes = cnt;
+            for (size_t j = 0; j < cnt; j++) {
+                const bool wr = !query && !too_many;
+                if (wr && offsets) offsets[j] = off;
+                size_t got = 0;
+                uint8_t *dst = wr && codes_out && !overflow ? codes_out + off : nullptr;
+                if (!rd_bytes_to(r, dst, dst ? codes_cap - off : 0, got, overflow)) return false;
+                if (wr && codes_out && !dst) overflow = true;
+                off += got;
+            }
+            if (!query && !too_many && offsets) offsets[cnt] = off;
         } else {
-            nts.resize(cnt);
-            for (size_t j = 0; j < cnt; j++) if (!rd_uint(r, nts[j])) return false;
+            n_nts = cnt;
+            for (size_t j = 0; j < cnt; j++) {
+                uint64_t v;
+                if (!rd_uint(r, v)) return false;
+                if (!query && !too_many && n_tokens) n_tokens[j] = v;
+            }
         }
         return true;
     });
-    if (!ok || r.bad || r.i != len || codes.size() != nts.size()) return HIPVOC_WIRE_E_MALFORMED;
-    *n_items = codes.size();
-    if (!offsets && !codes_out && !n_tokens) return HIPVOC_WIRE_VOCODE_BATCH;   // size query
-    if (codes.size() > max_items) return HIPVOC_WIRE_E_CAP;
-    size_t off = 0;
-    for (size_t j = 0; j < codes.size(); j++) {
-        if (offsets) offsets[j] = off;
-        if (n_tokens) n_tokens[j] = nts[j];
-        if (codes_out) {
-            if (off + codes[j].size() > codes_cap) return HIPVOC_WIRE_E_CAP;
-            if (!codes[j].empty()) memcpy(codes_out + off, codes[j].data(), codes[j].size());
-        }
-        off += codes[j].size();
-    }
-    if (offsets) offsets[codes.size()] = off;
+    if (!ok || r.bad || r.i != len || n_codes != n_nts) return HIPVOC_WIRE_E_MALFORMED;
+    *n_items = n_codes;
+    if (query) return HIPVOC_WIRE_VOCODE_BATCH;
+    if (too_many || overflow) return HIPVOC_WIRE_E_CAP;
     return HIPVOC_WIRE_VOCODE_BATCH;
+}
+
+int hipvoc_wire_parse_vocode_batch(const uint8_t *msg, size_t len, uint8_t *codes_out, size_t codes_cap,
+                                   size_t *offsets, uint64_t *n_tokens, size_t max_items, size_t *n_items) {
+    try {
+        return parse_vocode_batch_impl(msg, len, codes_out, codes_cap, offsets, n_tokens, max_items, n_items);
+    } catch (...) {
+        return HIPVOC_WIRE_E_MALFORMED;
+    }
 }
 
 size_t hipvoc_wire_encode_vocode(const int16_t *pcm, size_t n_samples, uint8_t *out, size_t cap) {

@@ -19,7 +19,7 @@ SAMPLES_PER_TOKEN = 1920        # src/worker/vocoder.rs:6
 SAMPLE_RATE = 24000             # src/protocol.rs:121
 
 EXPORTS = [
-    "hipvoc_device_count", "hipvoc_load", "hipvoc_max_tokens", "hipvoc_unit_samples", "hipvoc_run",
+    "hipvoc_device_count", "hipvoc_find_vocoder_model", "hipvoc_load", "hipvoc_max_tokens", "hipvoc_n_codebooks", "hipvoc_vocode_pcm16_batch", "hipvoc_unit_samples", "hipvoc_run",
     "hipvoc_decode", "hipvoc_decode_batch", "hipvoc_vocode_pcm16", "hipvoc_decode_units_device", "hipvoc_decode_units_device_noalloc",
     "hipvoc_sync",
     "hipvoc_stream", "hipvoc_group_units", "hipvoc_unit_macs", "hipvoc_num_stages", "hipvoc_debug_stage",
@@ -51,9 +51,12 @@ def load_library():
     L = C.CDLL(p)
     vp, i64p, sz = C.c_void_p, C.c_void_p, C.c_size_t
     L.hipvoc_device_count.restype = C.c_int
+    L.hipvoc_find_vocoder_model.argtypes = [C.c_char_p, C.c_char_p, sz]
     L.hipvoc_load.restype = vp
     L.hipvoc_load.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int]
     L.hipvoc_max_tokens.argtypes = [vp]
+    L.hipvoc_n_codebooks.argtypes = [vp]
+    L.hipvoc_vocode_pcm16_batch.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp]
     L.hipvoc_unit_samples.restype = C.c_int64
     L.hipvoc_unit_samples.argtypes = [vp]
     L.hipvoc_run.argtypes = [vp, i64p, C.c_int, vp, sz, C.POINTER(sz)]
@@ -82,6 +85,16 @@ def load_library():
 DTYPE_F32, DTYPE_BF16, DTYPE_BF16X3 = 0, 1, 2      # include/hipvoc.h: HIPVOC_DTYPE_*
 
 
+def find_vocoder_model(models_dir: str) -> str:
+    """find_vocoder_model (src/worker/mod.rs:792-813) for the hip-vocoder backend: first existing safetensors candidate."""
+    L = load_library()
+    buf = C.create_string_buffer(4096)
+    rc = L.hipvoc_find_vocoder_model(os.fsencode(models_dir), buf, len(buf))
+    if rc != 0:
+        raise HipVocError(rc, buf.value.decode() or "no vocoder model found")
+    return os.fsdecode(buf.value)
+
+
 class HipVocoder:
     """Vocoder: converts codec tokens -> audio waveform on one MI355X (vocoder.rs:14-18)."""
 
@@ -89,10 +102,13 @@ class HipVocoder:
         self._h = handle
         self._L = lib
         self.max_tokens = int(lib.hipvoc_max_tokens(handle))
+        self.n_codebooks = int(lib.hipvoc_n_codebooks(handle))      # 16 for the shipped decoder (vocoder.rs:62)
 
     @classmethod
     def load(cls, model_path: str, device: int = 0, unit_frames: int = 64, dtype: int = 0) -> "HipVocoder":
         L = load_library()
+        if os.path.isdir(model_path):                      # a models directory: the reference's discovery (mod.rs:792-813)
+            model_path = find_vocoder_model(model_path)
         h = L.hipvoc_load(os.fsencode(model_path), device, dtype, unit_frames)
         if not h:
             raise HipVocError(-6, L.hipvoc_last_error(None).decode())
@@ -118,7 +134,10 @@ class HipVocoder:
         """codes [n_tokens,16] i64 (or flat) -> f32 samples (Vocoder::synthesize, vocoder.rs:60-85)."""
         codes = np.ascontiguousarray(codes, dtype=np.int64).reshape(-1)
         if n_tokens is None:
-            n_tokens = codes.size // 16
+            n_tokens = codes.size // self.n_codebooks
+        # the reference panics on the slice codes[pos*16..(pos+chunk_len)*16] (vocoder.rs:69-72); here it is an error
+        if n_tokens < 0 or codes.size < n_tokens * self.n_codebooks:
+            raise HipVocError(-1, f"codes holds {codes.size} values, n_tokens*{self.n_codebooks} = {n_tokens * self.n_codebooks} needed")
         out = np.empty(max(n_tokens, 1) * SAMPLES_PER_TOKEN, dtype=np.float32)
         n = C.c_size_t(0)
         self._check(self._L.hipvoc_decode(self._h, codes.ctypes.data, n_tokens, out.ctypes.data, out.size, C.byref(n)))
@@ -127,6 +146,8 @@ class HipVocoder:
     def run(self, codes) -> np.ndarray:
         """One padded unit [max_tokens,16] -> all unit samples (OnnxVocoder::run, vocoder.rs:164-172)."""
         codes = np.ascontiguousarray(codes, dtype=np.int64).reshape(-1)
+        if codes.size < self.max_tokens * self.n_codebooks:
+            raise HipVocError(-1, f"run() needs max_tokens*{self.n_codebooks} = {self.max_tokens * self.n_codebooks} codes, got {codes.size}")
         out = np.empty(self.unit_samples, dtype=np.float32)
         n = C.c_size_t(0)
         self._check(self._L.hipvoc_run(self._h, codes.ctypes.data, self.max_tokens, out.ctypes.data, out.size, C.byref(n)))
@@ -135,19 +156,41 @@ class HipVocoder:
     def handle_vocode(self, codes_bytes: bytes, n_tokens: int) -> Tuple[bytes, int]:
         """i64-LE code bytes -> (i16-LE PCM bytes, n_samples)  (Worker::handle_vocode, mod.rs:507-531)."""
         buf = np.frombuffer(codes_bytes, dtype=np.uint8)
-        if buf.size < n_tokens * 16 * 8:
-            raise HipVocError(-1, "codes buffer shorter than n_tokens*16*8 bytes")
+        if n_tokens < 0 or buf.size < n_tokens * self.n_codebooks * 8:
+            raise HipVocError(-1, f"codes buffer shorter than n_tokens*{self.n_codebooks}*8 bytes")
         pcm = np.empty(max(n_tokens, 1) * SAMPLES_PER_TOKEN, dtype="<i2")
         n = C.c_size_t(0)
         self._check(self._L.hipvoc_vocode_pcm16(self._h, buf.ctypes.data, n_tokens, pcm.ctypes.data, pcm.size, C.byref(n)))
         return pcm[: n.value].tobytes(), int(n.value)
 
+    def handle_vocode_batch(self, codes_bytes: Sequence[bytes], n_tokens: Sequence[int]) -> List[Tuple[bytes, int]]:
+        """The VocodeBatch request: per item what handle_vocode returns, from one batched decode with the
+        f32 -> i16 conversion on the GPU (hipvoc_vocode_pcm16_batch)."""
+        B = len(n_tokens)
+        if len(codes_bytes) != B:
+            raise HipVocError(-1, "codes and n_tokens differ in length")
+        nq8 = self.n_codebooks * 8
+        for cb, n in zip(codes_bytes, n_tokens):
+            if n < 0 or len(cb) < n * nq8:
+                raise HipVocError(-1, f"codes buffer shorter than n_tokens*{self.n_codebooks}*8 bytes")
+        nf = np.array(list(n_tokens), dtype=np.int32)
+        blob = np.frombuffer(b"".join(bytes(cb[: n * nq8]) for cb, n in zip(codes_bytes, n_tokens)) or b"\0", dtype=np.uint8)
+        caps = nf.astype(np.int64) * SAMPLES_PER_TOKEN
+        off = np.zeros(max(B, 1), dtype=np.uint64)
+        if B:
+            off[1:B] = np.cumsum(caps)[:-1]
+        pcm = np.empty(max(int(caps.sum()), 1), dtype="<i2")
+        n_out = np.zeros(max(B, 1), dtype=np.uint64)
+        self._check(self._L.hipvoc_vocode_pcm16_batch(self._h, blob.ctypes.data, nf.ctypes.data, B, pcm.ctypes.data,
+                                                      off.ctypes.data, n_out.ctypes.data))
+        return [(pcm[int(off[b]): int(off[b]) + int(n_out[b])].tobytes(), int(n_out[b])) for b in range(B)]
+
     def synthesize_batch(self, seqs: Sequence[np.ndarray]) -> List[np.ndarray]:
         """Many utterances in one call (hipvoc_decode_batch)."""
-        arrs = [np.ascontiguousarray(s, dtype=np.int64).reshape(-1, 16) for s in seqs]
+        arrs = [np.ascontiguousarray(s, dtype=np.int64).reshape(-1, self.n_codebooks) for s in seqs]
         B = len(arrs)
         nf = np.array([a.shape[0] for a in arrs], dtype=np.int32)
-        codes = np.concatenate(arrs, axis=0) if B else np.zeros((0, 16), dtype=np.int64)
+        codes = np.concatenate(arrs, axis=0) if B else np.zeros((0, self.n_codebooks), dtype=np.int64)
         caps = nf.astype(np.int64) * SAMPLES_PER_TOKEN
         off = np.zeros(B, dtype=np.uint64)
         if B:
@@ -190,7 +233,7 @@ class HipVocoder:
         self._check(self._L.hipvoc_sync(self._h))
 
     def stage(self, codes, stage: int, cap_floats: int) -> np.ndarray:
-        codes = np.ascontiguousarray(codes, dtype=np.int64).reshape(-1, 16)
+        codes = np.ascontiguousarray(codes, dtype=np.int64).reshape(-1, self.n_codebooks)
         out = np.empty(cap_floats, dtype=np.float32)
         c, l = C.c_int(0), C.c_int64(0)
         self._check(self._L.hipvoc_debug_stage(self._h, codes.ctypes.data, codes.shape[0], stage, out.ctypes.data,

@@ -191,3 +191,82 @@ def test_worker_serves_the_orchestrators_pipelined_requests_in_order(pkg, synth,
         pcm = np.frombuffer(bytes(data["Vocode"][0]), dtype="<i2")
         assert np.array_equal(pcm, c2.vocode(r)), i
     assert c.ping()
+
+
+def _start(args):
+    exe = os.path.join(ROOT, "qwen3-tts_amd", "hipvoc-worker")
+    p = subprocess.Popen([exe] + args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    line = p.stdout.readline()
+    while line and "listening on" not in line:          # (a models directory prints the discovered file first)
+        line = p.stdout.readline()
+    assert "listening on" in line, line + p.stdout.read()
+    return p, int(line.split("listening on ")[1].split()[0].rsplit(":", 1)[1])
+
+
+def test_worker_fans_a_batch_out_over_handles_and_finds_its_model_in_a_directory(pkg, synth, worker, tmp_path):
+    """SURVEY 8f-2 "fans out over devices": the items of ONE VocodeBatch are spread over the device queues (`--devices 0,0`
+    = two handles on this box's GPU) and come back in request order, bit-equal to single requests.  The worker is given a
+    models DIRECTORY, as the reference's `worker -m <models>` is, and applies find_vocoder_model's candidate list to it
+    (mod.rs:792-813, here <dir>/vocoder/vocoder.safetensors)."""
+    import shutil
+    import signal
+    wire = pkg.wire
+    cfg = synth.SMALL
+    models = tmp_path / "models"
+    (models / "vocoder").mkdir(parents=True)
+    shutil.copy(os.path.join(tempfile.gettempdir(), "hipvoc_test_SMALL_0.safetensors"), models / "vocoder" / "vocoder.safetensors")
+    p, port = _start(["-r", "vocoder", "-m", str(models), "-b", "127.0.0.1:0", "--unit-frames", "4", "--devices", "0,0", "--contexts", "1"])
+    try:
+        seqs = [synth.make_codes(n, 800 + n, cfg) for n in (5, 1, 9, 4, 13, 2, 7, 8, 3)]
+        ref = wire.WorkerClient("127.0.0.1", worker)
+        want = [ref.vocode(s) for s in seqs]
+        ref.close()
+        c = wire.WorkerClient("127.0.0.1", port)
+        got = c.vocode_batch(seqs)
+        assert len(got) == 9 and all(np.array_equal(a, b) for a, b in zip(got, want))
+        c.close()
+        p.send_signal(signal.SIGTERM)
+        out = p.communicate(timeout=30)[0]
+        stats = [ln for ln in out.splitlines() if "stats:" in ln]
+        assert len(stats) == 2 and all(int(ln.split("jobs=")[1].split()[0]) > 0 for ln in stats), out
+        assert sum(int(ln.split("jobs=")[1].split()[0]) for ln in stats) == 9
+    finally:
+        if p.poll() is None:
+            p.kill()
+            p.wait()
+
+
+def test_worker_survives_hostile_requests(pkg, synth, worker):
+    """allocation sizes must not be attacker-controlled and nothing a request carries may end the process.
+    (1) a VocodeBatch whose array32 header claims 1e8 items in a 40-byte frame; (2) a frame that does not deserialize:
+    error response, then the connection is closed as read_request's Err arm does (mod.rs:642-651); (3) more frames than
+    --max-frames: error response, connection stays; the worker serves on after all of them."""
+    wire = pkg.wire
+    p, port = _start(["-m", os.path.join(tempfile.gettempdir(), "hipvoc_test_SMALL_0.safetensors"), "-b", "127.0.0.1:0",
+                      "--unit-frames", "4", "--max-frames", "50", "--max-items", "8"])
+    try:
+        c = wire.WorkerClient("127.0.0.1", port)
+        hostile = b"\x81" + msgpack.packb("VocodeBatch") + b"\x92" + b"\xdd" + struct.pack(">I", 100_000_000) + b"\x90" * 8
+        c.send_raw(hostile)
+        status, _, err = c.read_response()
+        assert status == "error" and "Deserialize" in err
+        with pytest.raises((ConnectionError, OSError)):        # closed after the malformed frame
+            c.ping()
+            c.ping()
+        c.close()
+        c = wire.WorkerClient("127.0.0.1", port)
+        with pytest.raises(wire.WorkerError, match="max-frames"):
+            c.vocode(synth.make_codes(51, 1, synth.SMALL))
+        with pytest.raises(wire.WorkerError, match="max-frames"):
+            c.vocode_batch([synth.make_codes(30, 1, synth.SMALL), synth.make_codes(30, 2, synth.SMALL)])
+        with pytest.raises(wire.WorkerError, match="max-items"):
+            c.vocode_batch([synth.make_codes(1, i, synth.SMALL) for i in range(9)])
+        ok = c.vocode(synth.make_codes(50, 1, synth.SMALL))
+        ref = wire.WorkerClient("127.0.0.1", worker)
+        assert np.array_equal(ok, ref.vocode(synth.make_codes(50, 1, synth.SMALL)))
+        ref.close()
+        assert c.ping()
+        c.close()
+    finally:
+        p.kill()
+        p.wait()

@@ -177,3 +177,85 @@ def test_safetensors_reader_survives_fuzzing_under_asan_ubsan(pkg, tmp_path):
     assert r.returncode == 0, r.stderr
     r = subprocess.run([exe, good, str(tmp_path / "scratch.safetensors")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "fuzz_safetensors OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_chunk_loop_and_exception_barrier_under_asan_ubsan(tmp_path):
+    """tests/native/fuzz_chunking.cpp: the host logic the decode entry points run before any device work (chunking.hpp:
+    unit walk, extents, code validation on unaligned bytes) against a literal restatement of vocoder.rs:65-82 on 20k
+    random batches, INT_MAX-frame extremes without overflow or allocation, and the C ABI's exception barrier
+    (abi_guard.hpp: injected bad_alloc / length_error / runtime_error / non-std throws come back as HIPVOC_E_NOMEM /
+    HIPVOC_E_INTERNAL), built with -fsanitize=address,undefined."""
+    import shutil
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    exe = str(tmp_path / "fuzz_chunking")
+    r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-o", exe,
+                        os.path.join(ROOT, "tests", "native", "fuzz_chunking.cpp")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "fuzz_chunking OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_every_extern_c_body_that_allocates_sits_behind_the_barrier():
+    """include/hipvoc.h promises that nothing is thrown across the boundary: every extern "C" function of hipvoc.cpp /
+    encoder.inc.cpp whose body builds a std::vector / std::string / plan goes through guarded() or a try block."""
+    for name in ("hipvoc.cpp", "encoder.inc.cpp", "wire.cpp", "discovery.cpp"):
+        src = open(os.path.join(ROOT, "qwen3-tts_amd", "csrc", name)).read()
+        ext = src[src.index('extern "C"'):]
+        # split into top-level function bodies: "\n}\n" ends one
+        for body in re.split(r"\n}\n", ext):
+            m = re.search(r"\n(?:static )?(?:[\w:\*]+ )+\**(hipvoc_\w+)\(", "\n" + body)
+            if not m:
+                continue
+            allocates = re.search(r"std::vector|std::string|get_plan|enc_run|fmt\(|new ", body)
+            if allocates:
+                assert "guarded(" in body or "try {" in body or "_impl(" in body, f"{name}: {m.group(1)} allocates outside the exception barrier"
+
+
+def test_find_vocoder_model_candidate_order(pkg, tmp_path):
+    """find_vocoder_model (src/worker/mod.rs:792-813) for this backend: ordered candidates, the role sub-directory that
+    download::ensure_models returns, and the reference's error wording when nothing is there."""
+    hv = pkg.hipvoc
+    d = tmp_path / "models"
+    d.mkdir()
+    with pytest.raises(pkg.HipVocError, match="No vocoder model found in"):
+        hv.find_vocoder_model(str(d))
+    (d / "vocoder.onnx").write_bytes(b"x")
+    with pytest.raises(pkg.HipVocError, match="ONNX/RKNN"):
+        hv.find_vocoder_model(str(d))
+    (d / "speech_tokenizer").mkdir()
+    (d / "speech_tokenizer" / "model.safetensors").write_bytes(b"x")
+    assert hv.find_vocoder_model(str(d)) == str(d / "speech_tokenizer" / "model.safetensors")
+    (d / "vocoder").mkdir()
+    (d / "vocoder" / "vocoder_64.safetensors").write_bytes(b"x")
+    assert hv.find_vocoder_model(str(d)) == str(d / "speech_tokenizer" / "model.safetensors")      # the directory itself first
+    assert hv.find_vocoder_model(str(d / "vocoder")) == str(d / "vocoder" / "vocoder_64.safetensors")
+    (d / "vocoder.safetensors").write_bytes(b"x")
+    assert hv.find_vocoder_model(str(d)) == str(d / "vocoder.safetensors")
+    (d / "vocoder.safetensors").unlink()
+    (d / "vocoder.safetensors").mkdir()                     # a directory of that name is not a model file
+    assert hv.find_vocoder_model(str(d)) == str(d / "speech_tokenizer" / "model.safetensors")
+
+
+def test_load_error_text_is_per_thread(pkg):
+    """hipvoc_last_error(NULL): the calling thread's own failed load, so concurrent loads (hipvoc-worker: contexts x
+    devices) cannot clobber or race on each other's message."""
+    import ctypes as C
+    import threading
+    L = pkg.load_library()
+    seen = {}
+
+    def run(i):
+        for _ in range(200):
+            h = L.hipvoc_load(None if i == 0 else f"/nonexistent/{i}.safetensors".encode(), 0, 7 if i == 1 else 0, 64)
+            assert not h
+            seen.setdefault(i, set()).add(L.hipvoc_last_error(None).decode())
+
+    ths = [threading.Thread(target=run, args=(i,)) for i in range(3)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert seen[0] == {"weights_path is NULL"}
+    assert len(seen[1]) == 1 and "dtype" in next(iter(seen[1]))
+    assert len(seen[2]) == 1

@@ -165,3 +165,34 @@ def test_shared_known_answers_fixture(wire):
     assert msgpack.packb(["ok", "Ping", None]) == b["response_ok_ping"]
     assert msgpack.packb(["error", "Init", "x"]) == b["response_error_init_x"]
     assert msgpack.packb(["ok", {"Vocode": [[0, 0x80], 1]}, None]) == b["response_ok_vocode_audio_00_80_n1"]
+
+
+def test_hostile_item_counts_allocate_nothing(wire):
+    """ADVICE r1: a VocodeBatch whose array32 header claims 1e8 items must not make the parser reserve memory for them;
+    a well-formed batch of a million EMPTY items is counted, and refused by max_items, without per-item allocations."""
+    import ctypes as C
+    import resource
+    L = wire._lib()
+    head = b"\x81" + msgpack.packb("VocodeBatch") + b"\x92"
+    before = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    lying = head + b"\xdd" + struct.pack(">I", 100_000_000) + b"\x90" * 8
+    assert wire.parse_vocode_batch(lying)[0] == wire.E_MALFORMED
+    n_items = 1_000_000
+    many = head + b"\xdd" + struct.pack(">I", n_items) + b"\x90" * n_items + b"\xdd" + struct.pack(">I", n_items) + b"\x00" * n_items
+    buf = np.frombuffer(many, dtype=np.uint8)
+    n = C.c_size_t(0)
+    assert L.hipvoc_wire_parse_vocode_batch(buf.ctypes.data, len(many), None, 0, None, None, 0, C.byref(n)) == wire.VOCODE_BATCH
+    assert n.value == n_items
+    off = np.zeros(9, dtype=np.uint64)
+    nts = np.zeros(8, dtype=np.uint64)
+    out = np.zeros(16, dtype=np.uint8)
+    rc = L.hipvoc_wire_parse_vocode_batch(buf.ctypes.data, len(many), out.ctypes.data, out.size, off.ctypes.data, nts.ctypes.data, 8, C.byref(n))
+    assert rc == wire.E_CAP and n.value == n_items
+    after = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    assert after - before < 64 * 1024, f"parser grew the process by {(after - before) / 1024:.0f} MiB"      # ru_maxrss is in KiB
+    # capacity: codes that do not fit are refused, never written past the buffer
+    seqs = [np.frombuffer(codes_bytes(2, 1), dtype="<i8").reshape(-1, 16)] * 3
+    msg = np.frombuffer(wire.request_vocode_batch(seqs), dtype=np.uint8)
+    small = np.full(300, 0xEE, dtype=np.uint8)
+    rc = L.hipvoc_wire_parse_vocode_batch(msg.ctypes.data, msg.size, small.ctypes.data, 256, off.ctypes.data, nts.ctypes.data, 8, C.byref(n))
+    assert rc == wire.E_CAP and np.all(small[256:] == 0xEE)
