@@ -3,8 +3,10 @@
 In the reference every ``max_tokens``-frame unit of every request is decoded with no carried state
 (src/worker/vocoder.rs:65-82), so both a batch of utterances and the segments of one long stream
 shard as contiguous ranges of units, one process per GPU.  The only communication is the optional
-gather of finished waveform shards to rank 0 (``torch.distributed`` all_gather_object / gather; with
-the ``nccl`` backend that is RCCL over xGMI, with ``gloo`` it runs on CPU for tests).
+gather of finished waveform shards to rank 0: ``UnitGather`` (one ``torch.distributed.gather`` of device
+buffers -- RCCL over xGMI with the ``nccl`` backend, CPU tensors with ``gloo`` in the tests), or
+``gather_stream`` for host arrays (``gather_object``: pickled through the process group, not a device
+collective).
 """
 from __future__ import annotations
 
@@ -48,6 +50,35 @@ def gather_stream(local: np.ndarray, rank: int, world: int, dist=None) -> np.nda
     if rank != 0:
         return None
     return np.concatenate(parts)
+
+
+class UnitGather:
+    """Gather of decoded units to rank 0 as ONE collective on tensors (device buffers with the ``nccl`` backend: RCCL over
+    xGMI; CPU tensors with ``gloo``), not pickled objects: every rank contributes a [max_units, stride] buffer (its shard,
+    zero-padded to the largest shard) and rank 0 receives world of them.  Buffers are allocated once, so a timed loop
+    allocates nothing.  ``stitch`` cuts the kept samples of each unit (vocoder.rs:79-80) out of the gathered rows in rank
+    order -- shards start on unit boundaries, so the result is bit-identical to a single-GPU decode."""
+
+    def __init__(self, n_units_total: int, stride: int, rank: int, world: int, dist, device):
+        import torch
+        self.rank, self.world, self.dist = rank, world, dist
+        self.ranges = [shard_range(n_units_total, r, world) for r in range(world)]
+        self.max_units = max(hi - lo for lo, hi in self.ranges)
+        self.pad = torch.zeros((self.max_units, stride), dtype=torch.float32, device=device)
+        self.parts = [torch.empty_like(self.pad) for _ in range(world)] if rank == 0 else None
+
+    def gather(self, local, n_local: int):
+        """local: [>= n_local, stride] tensor holding this rank's decoded units (complete on its device)."""
+        self.pad[:n_local] = local[:n_local]
+        self.dist.gather(self.pad, self.parts, dst=0)
+
+    def stitch(self, keep: Sequence[int]) -> np.ndarray:
+        """Rank 0: the stream's samples; keep[i] = samples kept of global unit i."""
+        out = []
+        for r, (lo, hi) in enumerate(self.ranges):
+            g = self.parts[r].cpu().numpy()
+            out.extend(g[i - lo, : keep[i]] for i in range(lo, hi))
+        return np.concatenate(out) if out else np.zeros(0, dtype=np.float32)
 
 
 def shard_utterances(n_utts: int, rank: int, world: int) -> range:
