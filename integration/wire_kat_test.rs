@@ -23,6 +23,11 @@ fn requests_serialize_to_the_known_answers() {
         hex(&rmp_serde::to_vec(&Request::Vocode { codes: vec![0x01, 0x80, 0xff], n_tokens: 0 }).unwrap()),
         "81a6566f636f6465929301cc80ccff00"
     );
+    // the appended variant (integration/protocol_vocode_batch.rs)
+    assert_eq!(
+        hex(&rmp_serde::to_vec(&Request::VocodeBatch { codes: vec![vec![0x01, 0x80], vec![0xff]], n_tokens: vec![0, 0] }).unwrap()),
+        "81ab566f636f6465426174636892929201cc8091ccff920000"
+    );
 }
 
 #[test]
@@ -42,6 +47,14 @@ fn responses_deserialize_from_the_known_answers() {
             assert_eq!(n_samples, 1);
         }
         _ => panic!("expected ResponseData::Vocode"),
+    }
+    let r: Response = rmp_serde::from_slice(&unhex("93a26f6b81ab566f636f6465426174636892929200cc8090920100c0")).unwrap();
+    match r.data {
+        ResponseData::VocodeBatch { audio, n_samples } => {
+            assert_eq!(audio, vec![vec![0x00, 0x80], vec![]]);
+            assert_eq!(n_samples, vec![1, 0]);
+        }
+        _ => panic!("expected ResponseData::VocodeBatch"),
     }
     // and the other direction: what the Rust worker would have sent is what the C encoder emits
     let back = rmp_serde::to_vec(&Response { status: "ok".into(), data: ResponseData::Vocode { audio: vec![0x00, 0x80], n_samples: 1 }, error: None }).unwrap();

@@ -120,7 +120,7 @@ static bool enc_load_model(Ctx *c, EncModel *m, const char *path, std::string &e
     if (m->n_heads < 1 || m->context < 1 || m->n_use < 1) { err = "bad metadata"; return false; }
     const std::string E = "encoder.encoder.layers.";
     const StTensor *w0 = L.st.find(E + "0.conv.weight");
-    if (!w0 || w0->shape.size() != 3 || w0->shape[1] != 1) { err = "missing/invalid " + E + "0.conv.weight"; return false; }
+    if (!w0 || w0->shape.size() != 3 || w0->shape[1] != 1 || w0->shape[0] < 1 || w0->shape[2] < 1) { err = "missing/invalid " + E + "0.conv.weight"; return false; }
     m->n_filters = (int)w0->shape[0];
     m->conv0 = enc_conv0(L, E + "0.conv");      // 1-tap GEMM over the tap stack of the waveform (launch_tap_stack)
     m->conv0_taps = (int)w0->shape[2];
@@ -129,7 +129,7 @@ static bool enc_load_model(Ctx *c, EncModel *m, const char *path, std::string &e
         EncModel::Blk b;
         b.C = C;
         const StTensor *dw = L.st.find(E + fmt("%d.conv.weight", idx + 2));
-        if (!dw || dw->shape.size() != 3 || dw->shape[2] % 2 || dw->shape[1] != C) { err = "missing/invalid down conv"; return false; }
+        if (!dw || dw->shape.size() != 3 || dw->shape[2] < 2 || dw->shape[2] % 2 || dw->shape[1] != C) { err = "missing/invalid down conv"; return false; }
         b.ratio = (int)dw->shape[2] / 2;
         b.c1 = enc_conv(L, E + fmt("%d.block.1.conv", idx));        // dilation 1 (193)
         b.c2 = enc_conv(L, E + fmt("%d.block.3.conv", idx));
@@ -169,7 +169,7 @@ static bool enc_load_model(Ctx *c, EncModel *m, const char *path, std::string &e
     m->n_layers = (int)m->layers.size();
     {
         const StTensor *dw = L.st.find("encoder.downsample.conv.weight");
-        if (!dw || dw->shape.size() != 3 || dw->shape[2] % 2) { err = "missing/invalid encoder.downsample.conv.weight"; return false; }
+        if (!dw || dw->shape.size() != 3 || dw->shape[2] < 2 || dw->shape[2] % 2) { err = "missing/invalid encoder.downsample.conv.weight"; return false; }
         m->ds_stride = (int)dw->shape[2] / 2;                       // kernel = 2 * stride (596)
         m->ds = enc_strided(L, "encoder.downsample.conv.weight", "encoder.downsample.conv.bias", m->ds_stride);
         if (!L.ok) { err = L.err; return false; }

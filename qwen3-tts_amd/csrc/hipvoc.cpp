@@ -375,7 +375,7 @@ struct Loader {
             std::vector<int64_t> sh;
             if (!get(wnames[i], ws[i], sh)) return g;
             if (sh.size() == 2) sh.push_back(1);
-            if (sh.size() != 3 || (i && (sh[1] != sh0[1] || sh[2] != sh0[2]))) {
+            if (sh.size() != 3 || sh[0] < 1 || sh[1] < 1 || sh[2] < 1 || (i && (sh[1] != sh0[1] || sh[2] != sh0[2]))) {
                 err = wnames[i] + ": unexpected shape";
                 ok = false;
                 return g;
@@ -409,7 +409,7 @@ struct Loader {
         std::vector<float> w;
         std::vector<int64_t> sh;
         if (!get(wname, w, sh)) return g;
-        if (sh.size() != 3 || (sh[2] != s && sh[2] != 2 * s)) {
+        if (s < 1 || sh.size() != 3 || sh[0] < 1 || sh[1] < 1 || (sh[2] != s && sh[2] != 2 * s)) {
             err = wname + ": transposed conv needs kernel == stride or 2*stride";
             ok = false;
             return g;
@@ -460,6 +460,7 @@ static bool load_model(Ctx *c, const char *path, std::string &err) {
     if (!e0 || e0->shape.size() != 2) { err = "missing/invalid rvq_first embedding_sum"; return false; }
     c->cb_size = (int)e0->shape[0];
     c->cb_dim = (int)e0->shape[1];
+    if (c->cb_size < 1 || c->cb_dim < 1) { err = "empty codebook"; return false; }
     int nrest = 0;
     while (L.st.has(D + fmt("quantizer.rvq_rest.vq.layers.%d._codebook.embedding_sum", nrest))) nrest++;
     c->n_q = 1 + nrest;
@@ -529,12 +530,14 @@ static bool load_model(Ctx *c, const char *path, std::string &err) {
     for (int i = 0; L.ok && L.st.has(D + fmt("upsample.%d.0.conv.weight", i)); i++) {
         std::string p = D + fmt("upsample.%d.", i);
         const StTensor *t = L.st.find(p + "0.conv.weight");
+        if (t->shape.size() != 3 || t->shape[2] < 1) { err = p + "0.conv.weight: expected [Cin][Cout][K], K >= 1"; return false; }
         int r = (int)t->shape[2];
         Ctx::Up u{};
         u.tc = L.transconv(p + "0.conv.weight", p + "0.conv.bias", r);
         std::vector<float> dw;
         std::vector<int64_t> sh;
         if (!L.get(p + "1.dwconv.conv.weight", dw, sh)) break;
+        if (sh.empty() || sh.back() < 1 || sh.back() > 64) { err = p + "1.dwconv.conv.weight: bad kernel size"; return false; }
         u.K = (int)sh.back();
         u.dw_w = L.upload(dw);
         u.dw_b = L.vec(p + "1.dwconv.conv.bias", c->latent);
@@ -555,6 +558,7 @@ static bool load_model(Ctx *c, const char *path, std::string &err) {
     for (; L.ok && L.st.has(D + fmt("decoder.%d.block.1.conv.weight", nb + 1)); nb++) {
         std::string p = D + fmt("decoder.%d.block.", nb + 1);
         const StTensor *t = L.st.find(p + "1.conv.weight");
+        if (t->shape.size() != 3 || t->shape[2] < 2 || (t->shape[2] & 1)) { err = p + "1.conv.weight: expected [Cin][Cout][2*stride]"; return false; }
         int r = (int)t->shape[2] / 2;
         Ctx::Block b{};
         b.s = L.snake(p + "0.", C);

@@ -5,6 +5,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <cstdint>
 #include <cstring>
 
 namespace hipvoc {
@@ -72,7 +73,10 @@ struct JParser {
         }
         if (p >= end || *p < '0' || *p > '9') return fail("expected integer");
         v = 0;
-        while (p < end && *p >= '0' && *p <= '9') v = v * 10 + (*p++ - '0');
+        while (p < end && *p >= '0' && *p <= '9') {
+            if (v > (INT64_MAX - 9) / 10) return fail("integer out of range");
+            v = v * 10 + (*p++ - '0');
+        }
         if (neg) v = -v;
         return true;
     }
@@ -89,8 +93,9 @@ struct JParser {
             return fail("expected , or ]");
         }
     }
-    bool skip_value() {   // strings, numbers, objects, arrays, literals
+    bool skip_value(int depth = 0) {   // strings, numbers, objects, arrays, literals
         ws();
+        if (depth > 32) return fail("nesting too deep");
         if (p >= end) return fail("eof");
         if (*p == '"') {
             std::string s;
@@ -105,7 +110,7 @@ struct JParser {
                     std::string k;
                     if (!str(k) || !lit(':')) return fail("bad object");
                 }
-                if (!skip_value()) return false;
+                if (!skip_value(depth + 1)) return false;
                 if (lit(',')) continue;
                 if (lit(close)) return true;
                 return fail("bad container");
@@ -221,9 +226,15 @@ bool SafeTensors::open(const std::string &path, std::string &err) {
                 t.data = data0 + offs[0];
                 t.nbytes = (size_t)(offs[1] - offs[0]);
                 size_t esz = t.dtype == "F32" ? 4 : (t.dtype == "F16" || t.dtype == "BF16") ? 2 : 0;
-                for (auto d : t.shape)
-                    if (d < 0) { err = "negative dim in " + key; return false; }
-                if (esz && (size_t)t.numel() * esz != t.nbytes) {
+                // every dim fits an int and the element count cannot overflow, whatever the dtype (the loader casts
+                // dims to int and sizes host vectors from numel())
+                uint64_t numel = 1;
+                for (auto d : t.shape) {
+                    if (d < 0 || d > 0x7fffffffLL) { err = "dim out of range in " + key; return false; }
+                    if (__builtin_mul_overflow(numel, (uint64_t)d, &numel) || numel > (1ull << 40)) { err = "tensor too large: " + key; return false; }
+                }
+                if (t.shape.size() > 8) { err = "too many dims in " + key; return false; }
+                if (esz && numel * esz != t.nbytes) {
                     err = "size mismatch for " + key;
                     return false;
                 }
@@ -253,6 +264,10 @@ bool SafeTensors::to_f32(const std::string &name, std::vector<float> &out, std::
     const StTensor *t = find(name);
     if (!t) {
         err = "missing tensor " + name;
+        return false;
+    }
+    if (t->dtype != "F32" && t->dtype != "BF16" && t->dtype != "F16") {      // before anything is sized from the header
+        err = "unsupported dtype " + t->dtype + " for " + name;
         return false;
     }
     shape = t->shape;

@@ -73,6 +73,33 @@ int main(int argc, char **argv) {
         }
         try_file(m, argv[2]);
     }
+    // hand-made hostile headers: products of dims that wrap around 2^64, integers beyond int64, dims beyond
+    // int, an unknown dtype with an absurd shape, unbounded nesting -- refused with a message, nothing sized from them
+    auto with_header = [](const std::string &h, size_t data) {
+        std::vector<uint8_t> m(8 + h.size() + data, 0);
+        uint64_t n = h.size();
+        memcpy(m.data(), &n, 8);
+        memcpy(m.data() + 8, h.data(), h.size());
+        return m;
+    };
+    const long before = oks;
+    const char *hostile[] = {
+        "{\"a.weight\":{\"dtype\":\"F32\",\"shape\":[4611686018427387904,4],\"data_offsets\":[0,0]}}",
+        "{\"a.weight\":{\"dtype\":\"F32\",\"shape\":[4294967296,4294967296,1],\"data_offsets\":[0,0]}}",
+        "{\"a.weight\":{\"dtype\":\"F32\",\"shape\":[99999999999999999999999999,1],\"data_offsets\":[0,4]}}",
+        "{\"a.weight\":{\"dtype\":\"F32\",\"shape\":[3000000000],\"data_offsets\":[0,4]}}",
+        "{\"a.weight\":{\"dtype\":\"I64\",\"shape\":[2147483647,2147483647,2147483647],\"data_offsets\":[0,8]}}",
+        "{\"a.weight\":{\"dtype\":\"F32\",\"shape\":[1],\"data_offsets\":[0,18446744073709551620]}}",
+    };
+    for (const char *h : hostile) try_file(with_header(h, 16), argv[2]);
+    if (oks != before) { fprintf(stderr, "a hostile header was accepted\n"); return 1; }
+    {
+        std::string deep = "{\"__metadata__\":{\"k\":";
+        deep += std::string(200000, '[');
+        deep += "}}";
+        try_file(with_header(deep, 0), argv[2]);
+        if (oks != before) { fprintf(stderr, "unbounded nesting was accepted\n"); return 1; }
+    }
     printf("fuzz_safetensors OK %ld files, %ld accepted\n", loads, oks);
     return 0;
 }

@@ -165,6 +165,12 @@ def test_shared_known_answers_fixture(wire):
     assert msgpack.packb(["ok", "Ping", None]) == b["response_ok_ping"]
     assert msgpack.packb(["error", "Init", "x"]) == b["response_error_init_x"]
     assert msgpack.packb(["ok", {"Vocode": [[0, 0x80], 1]}, None]) == b["response_ok_vocode_audio_00_80_n1"]
+    # the VocodeBatch extension (appended variants)
+    rc, codes, nts = wire.parse_vocode_batch(b["request_vocode_batch_codes_0180_ff_n00"])
+    assert rc == wire.VOCODE_BATCH and codes == [bytes([1, 0x80]), bytes([0xFF])] and nts == [0, 0]
+    assert wire.parse_request(b["request_vocode_batch_codes_0180_ff_n00"])[0] == wire.VOCODE_BATCH
+    got = wire.encode_vocode_batch_response([np.array([-32768], dtype=np.int16), np.zeros(0, dtype=np.int16)])
+    assert got == b["response_ok_vocode_batch_audio_0080_empty_n10"]
 
 
 def test_hostile_item_counts_allocate_nothing(wire):
