@@ -46,6 +46,19 @@ static std::string fmt(const char *f, ...) {
 }
 
 static inline int rup(int v, int m) { return (v + m - 1) / m * m; }
+// Padded row length of an activation tensor (floats).  The kernels need a multiple of 4 (16-byte vector accesses); 32 would make
+// every row and every 256-position tile start on a 128-byte line (HIPVOC_LPAD): measured, no change in time or HBM traffic
+// in any mode (profiles/r02_lpad_compare.txt), so the default stays 4.
+static int lpad() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("HIPVOC_LPAD");
+        v = e ? atoi(e) : 4;
+        if (v < 4 || (v & 3)) v = 4;
+    }
+    return v;
+}
+static inline int rowlen(int L) { return rup(L, lpad()); }
 static inline long rupl(long v, long m) { return (v + m - 1) / m * m; }
 
 // One conv / linear / transposed conv, packed for conv_gemm.
@@ -86,6 +99,7 @@ struct Step {
     const char *name;
     const char *kernel;    // device kernel symbol family (matches rocprofv3 kernel names)
     double macs;           // per pass (all G units)
+    double bytes = 0;      // algorithmic HBM bytes per pass: activations read + written (+ residual); weights excluded
     int stage;             // stage id this step completes, or -1
     const float *out;      // where that stage's tensor lives
     int C, L, Lp;
@@ -663,7 +677,7 @@ struct PlanBuilder {
     }
 
     void add(const char *name, const char *kernel, double macs, std::function<hipError_t(hipStream_t)> f) {
-        p->steps.push_back(Step{std::move(f), name, kernel, macs, -1, nullptr, 0, 0, 0});
+        p->steps.push_back(Step{std::move(f), name, kernel, macs, 0.0, -1, nullptr, 0, 0, 0});
     }
     void mark(int stage, const float *out, int C, int L, int Lp) {
         Step &s = p->steps.back();
@@ -694,6 +708,11 @@ struct PlanBuilder {
         a.x_cs = (long)G * Lpi; a.y_cs = (long)G * Lpo;
         double macs = (double)G * M * g.N * g.Cin * g.ntaps;
         add(name, conv_gemm_kernel_name(a), macs, [a](hipStream_t s) { return launch_conv_gemm(a, s); });
+        {
+            const double in_el = (double)g.Cin * G * Lin, out_el = (double)(g.N / g.S) * G * ((double)M * g.S);
+            p->steps.back().bytes = in_el * (xb ? 2 : 4) + (y ? out_el * 4 : 0) + (yb ? out_el * 2 : 0) + (post && y2 ? out_el * 4 : 0) +
+                                    (res ? out_el * 4 : 0);
+        }
     }
 
     // fused residual unit: y = x + c2(snake2(c1(snake1(x)))) in one launch (in place on x is NOT allowed:
@@ -716,6 +735,10 @@ struct PlanBuilder {
         a.units = G; a.M = L; a.Lin = L; a.x_us = Lp; a.y_us = Lp; a.x_cs = (long)G * Lp; a.y_cs = (long)G * Lp;
         double macs = (double)G * L * c1.N * ((double)c1.Cin * c1.ntaps + c2.Cin);
         add(name, conv_gemm_kernel_name(a), macs, [a](hipStream_t s) { return launch_conv_gemm(a, s); });
+        {
+            const double el = (double)c1.N * G * L;      // operand in (packed or fp32), fp32 residual in, fp32 / packed out
+            p->steps.back().bytes = el * (xb ? 2 : 4) + (xb ? el * 4 : 0) + (y ? el * 4 : 0) + (yb ? el * 2 : 0);
+        }
     }
 };
 
@@ -733,7 +756,7 @@ static std::unique_ptr<Plan> build_plan(Ctx *c, int G, int T, bool debug, char *
         ~Used() { if (used) *used = b.soff; }
     } report{b, used};
     int st = 0;
-    const int Tp = rup(T, 4);
+    const int Tp = rowlen(T);
     // g1 RVQ
     float *rvq = b.buf(B_RVQ, (size_t)c->q_out * G * Tp);
     float *sums = b.buf(B_SUMS, (size_t)2 * c->cb_dim * G * Tp);
@@ -798,19 +821,19 @@ static std::unique_ptr<Plan> build_plan(Ctx *c, int G, int T, bool debug, char *
     {
         long L = T;
         int C = c->latent;
-        big = std::max(big, (size_t)C * rup((int)L, 4));
+        big = std::max(big, (size_t)C * rowlen((int)L));
         for (size_t i = 0; i < c->ups.size(); i++) {
             L *= c->up_ratio[i];
-            big = std::max(big, (size_t)C * rup((int)L, 4));
-            big2 = std::max(big2, (size_t)c->ups[i].pw1.N * rup((int)L, 4));
+            big = std::max(big, (size_t)C * rowlen((int)L));
+            big2 = std::max(big2, (size_t)c->ups[i].pw1.N * rowlen((int)L));
         }
-        big = std::max(big, (size_t)c->dec_dim * rup((int)L, 4));
+        big = std::max(big, (size_t)c->dec_dim * rowlen((int)L));
         C = c->dec_dim;
         for (size_t i = 0; i < c->blocks.size(); i++) {
             L = c->tc_len(L, c->rates[i]);
             C = c->blocks[i].tc.N / c->rates[i];
-            big = std::max(big, (size_t)C * rup((int)L, 4));
-            if (c->dual_out >= 2 && !blk_fused(c->blocks[i])) snk_floats = std::max(snk_floats, (size_t)C * rup((int)L, 4) * G);
+            big = std::max(big, (size_t)C * rowlen((int)L));
+            if (c->dual_out >= 2 && !blk_fused(c->blocks[i])) snk_floats = std::max(snk_floats, (size_t)C * rowlen((int)L) * G);
         }
         big *= G;
         big2 *= G;
@@ -825,7 +848,7 @@ static std::unique_ptr<Plan> build_plan(Ctx *c, int G, int T, bool debug, char *
     // g4 upsample
     for (size_t i = 0; i < c->ups.size(); i++) {
         const Ctx::Up &u = c->ups[i];
-        int L2 = L * c->up_ratio[i], Lp2 = rup(L2, 4);
+        int L2 = L * c->up_ratio[i], Lp2 = rowlen(L2);
         b.gemm("up_transconv", u.tc, cur, L, Lp, t1, Lp2, nullptr, nullptr, nullptr, ACT_NONE);
         std::swap(cur, t1);
         L = L2; Lp = Lp2;
@@ -872,7 +895,7 @@ static std::unique_ptr<Plan> build_plan(Ctx *c, int G, int T, bool debug, char *
         for (size_t bi = 0; bi < c->blocks.size(); bi++) {
             const Ctx::Block &blk = c->blocks[bi];
             const int r = c->rates[bi];
-            const int L2 = (int)c->tc_len(L, r), Lp2 = rup(L2, 4);
+            const int L2 = (int)c->tc_len(L, r), Lp2 = rowlen(L2);
             const size_t ni = std::min<size_t>(bi, 4);
             const bool fused_blk = blk_fused(blk);
             // trans-conv: packed in; fp32 x0 (the residual stream) and packed snake_s1(x0) out
@@ -920,7 +943,7 @@ static std::unique_ptr<Plan> build_plan(Ctx *c, int G, int T, bool debug, char *
         for (size_t bi = 0; bi < c->blocks.size(); bi++) {
             const Ctx::Block &blk = c->blocks[bi];
             int r = c->rates[bi];
-            int L2 = (int)c->tc_len(L, r), Lp2 = rup(L2, 4);
+            int L2 = (int)c->tc_len(L, r), Lp2 = rowlen(L2);
             size_t ni = std::min<size_t>(bi, 4);
             // Un-fused residual units (blocks whose channels do not fit one row tile): every SnakeBeta of the chain is
             // evaluated by the PRODUCER of the tensor it acts on, once per element, instead of in the consumer's
@@ -968,6 +991,7 @@ static std::unique_ptr<Plan> build_plan(Ctx *c, int G, int T, bool debug, char *
         b.add("final_conv7", "final_conv_kernel<7>", (double)G * L * g.Cin * g.ntaps, [=](hipStream_t s) {
             return launch_final_conv(x, cc->cur_out, w, bias, sa, sib, Cf, 7, GG, LL, LLp, cc->cur_out_stride, s);
         });
+        plan->steps.back().bytes = ((double)g.Cin + 1.0) * G * L * 4;
         b.mark(st++, nullptr, 1, L, 0);
     } else {
         ConvGemmArgs a{};
@@ -1028,9 +1052,13 @@ static int run_plan(Ctx *c, Plan *p, const long long *d_codes, float *d_out, lon
         for (auto &e : ev) HIPCHK(hipEventCreate(&e));
         HIPCHK(hipEventRecord(ev[0], c->stream));
     }
+    // HIPVOC_TRACE_STEPS=1: the launch sequence of every pass on stderr, for tools that attribute per-dispatch profiler
+    // rows (rocprofv3 counter CSVs are in dispatch order) to steps: "HIPVOC_STEP <index> <step> <kernel> <macs> <bytes>"
+    static const bool trace_steps = getenv("HIPVOC_TRACE_STEPS") != nullptr;
     size_t ran = 0;
     for (size_t i = 0; i < p->steps.size(); i++) {
         const Step &s = p->steps[i];
+        if (trace_steps) fprintf(stderr, "HIPVOC_STEP %zu %s %s %.0f %.0f\n", i, s.name, s.kernel, s.macs, s.bytes);
         hipError_t e = s.run(c->stream);
         if (e != hipSuccess) {
             c->err = fmt("launch of %s failed: %s", s.name, hipGetErrorString(e));

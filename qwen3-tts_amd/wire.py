@@ -223,3 +223,65 @@ class WorkerClient:
             assert pcm.size == n_samples
             parts.append(pcm)
         return np.concatenate(parts) if parts else np.zeros(0, dtype=np.int16)
+
+
+class VocoderQueue:
+    """Host-side mirror of integration/pipeline_vocode_batch.rs (the orchestrator's batched vocoder requests, SURVEY.md
+    8f-1): one thread owns the vocoder connection; ``submit`` never blocks and returns a future; whenever the connection is
+    free, EVERYTHING that is waiting -- chunks of one utterance and of other concurrent utterances -- goes out as one
+    ``VocodeBatch`` (a lone submission as the reference's plain ``Vocode``).  Callers keep the order of their own audio by
+    waiting for their futures in submission order, as pipeline.rs:659-673 reads its responses."""
+
+    def __init__(self, host: str, port: int, max_batch: int = 256):
+        import queue
+        import threading
+        self._q = queue.Queue()
+        self._client = WorkerClient(host, port)
+        self._max = max_batch
+        self.batches_sent = 0
+        self.singles_sent = 0
+        self._th = threading.Thread(target=self._run, daemon=True)
+        self._th.start()
+
+    def submit(self, codes: np.ndarray):
+        from concurrent.futures import Future
+        f = Future()
+        self._q.put((np.ascontiguousarray(codes, dtype=np.int64).reshape(-1, 16), f))
+        return f
+
+    def close(self):
+        self._q.put(None)
+        self._th.join(timeout=30)
+        self._client.close()
+
+    def _run(self):
+        import queue
+        while True:
+            item = self._q.get()
+            if item is None:
+                return
+            batch = [item]
+            stop = False
+            while len(batch) < self._max:
+                try:
+                    nxt = self._q.get_nowait()
+                except queue.Empty:
+                    break
+                if nxt is None:
+                    stop = True
+                    break
+                batch.append(nxt)
+            try:
+                if len(batch) == 1:
+                    self.singles_sent += 1
+                    batch[0][1].set_result(self._client.vocode(batch[0][0]))
+                else:
+                    self.batches_sent += 1
+                    for (_, f), pcm in zip(batch, self._client.vocode_batch([c for c, _ in batch])):
+                        f.set_result(pcm)
+            except Exception as e:  # noqa: BLE001
+                for _, f in batch:
+                    if not f.done():
+                        f.set_exception(e)
+            if stop:
+                return

@@ -270,3 +270,37 @@ def test_worker_survives_hostile_requests(pkg, synth, worker):
     finally:
         p.kill()
         p.wait()
+
+
+def test_orchestrator_queue_coalesces_concurrent_utterances_into_vocode_batches(pkg, synth, worker):
+    """SURVEY 8f-1, orchestrator side (mirror of integration/pipeline_vocode_batch.rs): three utterances are "generated"
+    concurrently, each submitting its 4-token chunks as they appear and its tail last; the queue owns the one vocoder
+    connection and sends whatever is waiting as ONE VocodeBatch.  Every utterance's audio, assembled in its own submission
+    order, equals the reference's streamed single requests bit for bit."""
+    import threading
+    wire = pkg.wire
+    cfg = synth.SMALL
+    utts = [synth.make_codes(n, 600 + n, cfg) for n in (23, 9, 14)]
+    ref = wire.WorkerClient("127.0.0.1", worker)
+    want = [ref.vocode_streamed(u, chunk_size=4) for u in utts]
+    ref.close()
+    q = wire.VocoderQueue("127.0.0.1", worker)
+    got = [None] * len(utts)
+    gate = threading.Barrier(len(utts))
+
+    def synthesize(i):
+        gate.wait(timeout=30)
+        u = utts[i]
+        futs = [q.submit(u[s: s + 4]) for s in range(0, u.shape[0], 4)]        # full chunks, then the tail
+        got[i] = np.concatenate([f.result(timeout=60) for f in futs])           # "collect responses in submission order"
+
+    ths = [threading.Thread(target=synthesize, args=(i,)) for i in range(len(utts))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=120)
+    q.close()
+    for g, w in zip(got, want):
+        assert g is not None and np.array_equal(g, w)
+    assert q.batches_sent >= 1, "nothing was ever coalesced"
+    assert q.batches_sent + q.singles_sent < sum((u.shape[0] + 3) // 4 for u in utts)
