@@ -64,6 +64,7 @@ static inline long rupl(long v, long m) { return (v + m - 1) / m * m; }
 // One conv / linear / transposed conv, packed for conv_gemm.
 struct Gemm {
     float *w = nullptr;      // device [ntaps][CinP][NP] (fp32 mode)
+    float *ww = nullptr;     // fp32 mode, k = 7 convs that qualify: Winograd F(2,7) weights [8][CinP][NP] (kernels_wino.hip)
     unsigned short *wb = nullptr;    // bf16 mode: [ntaps][CinP/32][4][NP][8] bf16 (kernels_bf16.hip)
     unsigned short *wb2 = nullptr;   // bf16 mode, 1x1 conv of a fusable residual unit: accumulator-order packing
     unsigned short *wbm = nullptr, *wb2m = nullptr;   // bf16x3 mode: the mid planes bf16(w - hi) of wb / wb2
@@ -124,6 +125,8 @@ struct Ctx {
     bool post_snake = true;
     bool phase_major = true;   // transposed-conv rows phase-major (HIPVOC_PHASE_MAJOR=0: channel-major)
     bool packed = true;        // bf16 mode: GEMM-to-GEMM tensors of the decoder stack exchanged as packed bf16 (HIPVOC_PACKED=0: fp32)
+    bool wino_unfuse = true;   // blocks whose residual units could be fused run un-fused when their conv7 has a Winograd form (HIPVOC_WINO_UNFUSE=0)
+    bool wino = true;          // fp32 mode: k = 7 convs of the un-fused residual units by Winograd F(2,7) (HIPVOC_WINO=0: direct)
     bool trim_right = false;   // trans-conv trim policy (metadata transconv_trim_right_only=1): keep L*r samples instead of (L-1)*r
     bool is_encoder = false;   // handle made by hipvoc_enc_load (encoder.inc.cpp): the vocoder entry points refuse it
     bool bf16 = false;         // HIPVOC_DTYPE_BF16: conv-GEMM operands in bf16, fp32 accumulate, everything else fp32
@@ -412,6 +415,31 @@ struct Loader {
             n0 += Co;
         }
         finish(g, p, CinP);
+        // Winograd F(2,7) form of the k = 7 convs (fp32 mode): U_k = sum_j G[k][j] w_j for the points 0, +-1, +-2, +-1/2, inf,
+        // in double, rounded once.  Used when the layer qualifies (kernels_wino.hip: wino_selected).
+        if (c->wino && !c->bf16 && K == 7 && g.N == g.NP && g.N % 64 == 0 && Cin % 16 == 0 && (dil == 1 || dil == 3 || dil == 9)) {
+            static const double Gm[8][7] = {
+                {1, 0, 0, 0, 0, 0, 0},
+                {-2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9},
+                {-2.0 / 9, 2.0 / 9, -2.0 / 9, 2.0 / 9, -2.0 / 9, 2.0 / 9, -2.0 / 9},
+                {1.0 / 90, 2.0 / 90, 4.0 / 90, 8.0 / 90, 16.0 / 90, 32.0 / 90, 64.0 / 90},
+                {1.0 / 90, -2.0 / 90, 4.0 / 90, -8.0 / 90, 16.0 / 90, -32.0 / 90, 64.0 / 90},
+                {64.0 / 90, 32.0 / 90, 16.0 / 90, 8.0 / 90, 4.0 / 90, 2.0 / 90, 1.0 / 90},
+                {64.0 / 90, -32.0 / 90, 16.0 / 90, -8.0 / 90, 4.0 / 90, -2.0 / 90, 1.0 / 90},
+                {0, 0, 0, 0, 0, 0, 1}};
+            const size_t plane = (size_t)CinP * g.NP;
+            std::vector<float> u(8 * plane);
+            for (size_t e = 0; e < plane; e++) {
+                double w7[7];
+                for (int j = 0; j < 7; j++) w7[j] = p[(size_t)j * plane + e];
+                for (int k = 0; k < 8; k++) {
+                    double acc = 0;
+                    for (int j = 0; j < 7; j++) acc += Gm[k][j] * w7[j];
+                    u[(size_t)k * plane + e] = (float)acc;
+                }
+            }
+            g.ww = upload(u);
+        }
         if (!bias_name.empty()) g.bias = vec(bias_name, N);
         return g;
     }
@@ -691,6 +719,7 @@ struct PlanBuilder {
         ConvGemmArgs a{};
         a.in_elu = in_elu;
         a.s2d = s2d;
+        a.ww = g.ww;
         a.x = x; a.y = y; a.w = g.w; a.wb = g.wb; a.wbm = g.wbm; a.bias = g.bias; a.res = res; a.rscale = rscale; a.y2 = post ? y2 : nullptr;
         a.xb = xb; a.yb = yb;
         a.psn_a = post ? post->ea : nullptr; a.psn_ib = post ? post->ib : nullptr;
@@ -813,7 +842,15 @@ static std::unique_ptr<Plan> build_plan(Ctx *c, int G, int T, bool debug, char *
         xn = h;
     }
     // big ping-pong buffers: size = the largest decoder-side tensor
-    auto blk_fused = [c](const Ctx::Block &blk) {
+    // Winograd form of a block's k = 7 convs (fp32; kernels_wino.hip) exists when the loader made the transformed weights.
+    // Such a block runs UN-fused (the Winograd kernel keeps 8 accumulator sets per row tile, so a whole residual unit
+    // does not fit one workgroup) and with SnakeBeta in the producers' epilogues (dual outputs: the raw residual stream
+    // and the activated tensor side by side), so that the conv reads its operand straight into LDS by DMA.
+    auto blk_wino = [c](const Ctx::Block &blk) {
+        return c->wino && !c->bf16 && blk.res[0].c1.ww && blk.res[1].c1.ww && blk.res[2].c1.ww;
+    };
+    auto blk_fused = [c, blk_wino](const Ctx::Block &blk) {
+        if (c->wino_unfuse && blk_wino(blk)) return false;
         return c->fuse_res && PlanBuilder::can_fuse(blk.res[0].c1, blk.res[0].c2) &&
                PlanBuilder::can_fuse(blk.res[1].c1, blk.res[1].c2) && PlanBuilder::can_fuse(blk.res[2].c1, blk.res[2].c2);
     };
@@ -833,7 +870,7 @@ static std::unique_ptr<Plan> build_plan(Ctx *c, int G, int T, bool debug, char *
             L = c->tc_len(L, c->rates[i]);
             C = c->blocks[i].tc.N / c->rates[i];
             big = std::max(big, (size_t)C * rowlen((int)L));
-            if (c->dual_out >= 2 && !blk_fused(c->blocks[i])) snk_floats = std::max(snk_floats, (size_t)C * rowlen((int)L) * G);
+            if ((c->dual_out >= 2 || blk_wino(c->blocks[i])) && !blk_fused(c->blocks[i])) snk_floats = std::max(snk_floats, (size_t)C * rowlen((int)L) * G);
         }
         big *= G;
         big2 *= G;
@@ -951,7 +988,7 @@ static std::unique_ptr<Plan> build_plan(Ctx *c, int G, int T, bool debug, char *
             // and snake_s1(x) side by side; conv7 writes snake_s2(H) only.  Same fp32 operations on the same values,
             // so results are bit-identical to the consumer-side form.
             const bool fused_blk = blk_fused(blk);
-            const bool dual = c->dual_out >= 2 && !fused_blk;
+            const bool dual = (c->dual_out >= 2 || blk_wino(blk)) && !fused_blk;
             const int Cn = blk.tc.N / r;
             float *snk = dual ? snk_buf : nullptr;
             b.gemm(tc_names[ni], blk.tc, cur, L, Lp, t1, Lp2, post_snake ? nullptr : &blk.s, nullptr, nullptr, ACT_NONE,
@@ -1332,6 +1369,8 @@ static void *load_impl(const char *weights_path, int device_id, int dtype, int u
     if (const char *ps = getenv("HIPVOC_DUAL")) c->dual_out = atoi(ps);
     if (const char *ps = getenv("HIPVOC_PACKED")) c->packed = atoi(ps) != 0;
     if (const char *ps = getenv("HIPVOC_PHASE_MAJOR")) c->phase_major = atoi(ps) != 0;
+    if (const char *ps = getenv("HIPVOC_WINO")) c->wino = atoi(ps) != 0;
+    if (const char *ps = getenv("HIPVOC_WINO_UNFUSE")) c->wino_unfuse = atoi(ps) != 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
     {   // this device's copy of the static scratch array of hipvoc_decode_units_device_noalloc (scratch.hip): resolved
         // here, once per device, with the device current

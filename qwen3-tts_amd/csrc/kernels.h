@@ -52,6 +52,10 @@ struct ConvGemmArgs {
     // may be null when nobody needs it; y2 is not used together with yb; needs (N/S) % 8 == 0).
     const unsigned short *xb;
     unsigned short *yb;
+    // fp32 mode, causal k = 7 convs: the Winograd F(2,7)-transformed weights [8 points][CinP][NP] (kernels_wino.hip); when
+    // set and the layer qualifies (wino_selected) the conv runs on wino_conv7_kernel -- at EVERY launch size, so that
+    // batch == single holds bit for bit -- else on the direct kernels from `w`
+    const float *ww;
     int Cin, N, NP, TN;
     int ntaps, shift0, shift_step;   // shift(tap) = shift0 + tap*shift_step
     int S;                           // out channel = n / S, out position = m*S + n % S
@@ -84,6 +88,9 @@ bool convs_bf16_selected(const ConvGemmArgs &a);      // conv7 on a small launch
 hipError_t launch_convs_bf16(const ConvGemmArgs &a, hipStream_t s);
 const char *convs_bf16_kernel_name(const ConvGemmArgs &a);
 const char *conv_gemm_bf16_kernel_name(const ConvGemmArgs &a);
+bool wino_selected(const ConvGemmArgs &a);            // kernels_wino.hip: F(2,7) Winograd form of the fp32 k = 7 convs
+hipError_t launch_wino_conv7(const ConvGemmArgs &a, hipStream_t s);
+const char *wino_kernel_name(const ConvGemmArgs &a);
 size_t conv_gemm_bf16_lds_bytes(const ConvGemmArgs &a);
 namespace detail {
 void conv_gemm_geometry(const ConvGemmArgs &a, int &HL, int &XW, int bm = 256);   // halo (left, multiple of 4) and LDS tile width for bm positions

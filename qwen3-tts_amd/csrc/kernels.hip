@@ -378,6 +378,7 @@ using detail::conv_gemm_launch_tn;
 
 const char *conv_gemm_kernel_name(const ConvGemmArgs &a) {
     if (a.wb) return conv_gemm_bf16_kernel_name(a);
+    if (wino_selected(a)) return wino_kernel_name(a);
     if (gemm1_selected(a)) return gemm1_kernel_name(a);
     if (convs_selected(a)) return convs_kernel_name(a);
     static char names[3][2][8][48];
@@ -419,6 +420,7 @@ static hipError_t conv_gemm_launch_one(const ConvGemmArgs &a, int HL, int XW, in
 
 hipError_t launch_conv_gemm(const ConvGemmArgs &a_in, hipStream_t s) {
     if (a_in.wb) return launch_conv_gemm_bf16(a_in, s);
+    if (wino_selected(a_in)) return launch_wino_conv7(a_in, s);
     if (gemm1_selected(a_in)) return launch_gemm1(a_in, s);
     if (convs_selected(a_in)) return launch_convs(a_in, s);
     ConvGemmArgs a = a_in;

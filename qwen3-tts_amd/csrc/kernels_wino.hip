@@ -1,0 +1,313 @@
+// gfx950 (CDNA4 / MI355X): the causal k = 7 convolutions of the decoder blocks by Winograd / Cook-Toom F(2,7), fp32.
+//
+// The fp32 path is bound by v_mfma_f32_32x32x2_f32 (157 TFLOP/s; the direct implicit-GEMM kernel of kernels.hip reaches
+// 0.84 of it), so the only way past that roof in true fp32 arithmetic is FEWER multiplications.  F(2,7) computes two
+// outputs of a 7-tap filter from 8 products instead of 14:
+//     y[p], y[p+d]  =  A^T [ (G g) * (B^T x) ],     x = the eight inputs x[p - 6d + i d], i = 0..7  (d = dilation),
+// with the interpolation points 0, +-1, +-2, +-1/2, inf.  Summed over input channels each of the eight "points" is an
+// ordinary GEMM,  M_k[co][tile] = sum_ci U_k[co][ci] V_k[ci][tile]  (U = G g, transformed once at load; V = B^T x,
+// transformed on the fly), so the matrix cores do 8/14 = 4/7 of the direct kernel's work.  Rounding: the transforms'
+// constants are small (|B^T| <= 5.25, |A^T| <= 2); measured on a C = 384 layer the fp32 error is 5x the direct kernel's
+// (1.8e-6 of the output rms against 3.6e-7), a factor the whole path's margin to the 1e-3 / 60 dB gates absorbs
+// (DESIGN.md section 4b has the measured waveform figures).
+//
+// Orientation as everywhere: weights are the A operand (rows = output channels), activations the B operand (column =
+// TILE on the lane).  A workgroup of 4 waves owns 64 output channels x 128 tiles (256 positions); wave w the tiles
+// [32w, 32w+32); every lane keeps 8 points x 2 row tiles = 16 accumulator tiles (256 registers: one wave per SIMD, one
+// workgroup per CU -- the K loop below is software-pipelined instead of relying on other waves).  K loop over blocks of
+// 16 input channels: the raw activation window Xs[16][XW] (SnakeBeta applied once per element at commit, as in
+// conv_gemm_kernel) and the eight transformed weight tiles Ws[8][16][64] are double-buffered in LDS, fetched one block
+// ahead through registers; ONE barrier per block (128 MFMAs per wave between barriers).  A lane reads its eight inputs
+// of channel k from Xs, forms the eight V_k (24 VALU instructions) and feeds each to the two MFMAs of its point.
+//
+// Dilation: tile T of a unit is the output pair (p, p + d) with p = 2d (T / d) + T % d, so consecutive tiles are
+// (almost) consecutive positions and both the LDS reads and the stores stay on neighbouring addresses.
+#include "kernels.h"
+#include "device_common.h"
+
+#include <cstdio>
+#include <cstdlib>
+
+namespace hipvoc {
+
+static constexpr int WN_BK = 16;      // input channels per K stage
+static constexpr int WN_NT = 128;     // tiles per workgroup (4 waves x 32)
+static constexpr int WN_NTH = 256;
+static constexpr int WN_BN = 64;      // output channels per workgroup (2 row tiles)
+static constexpr int WN_PTS = 8;
+
+template <int D>
+struct WinoGeom {
+    static constexpr int XW = (257 + 10 * D + 3) & ~3;                    // raw window: see the bound in launch_wino_conv7
+    static constexpr int XP = (WN_BK * (XW / 4) + WN_NTH - 1) / WN_NTH;   // LDS-DMA pieces (16 B per lane) of the window per thread
+    static constexpr int XBUF = XP * WN_NTH * 4;                          // floats per window buffer (whole pieces: the tail is padding)
+};
+static constexpr int WN_WBUF = WN_PTS * WN_BK * WN_BN;                    // floats per weight buffer
+
+typedef __attribute__((address_space(1))) const void *wn_gptr_t;
+typedef __attribute__((address_space(3))) void *wn_lptr_t;
+
+// SN: the conv has a SnakeBeta prologue (a.sn_a / a.sn_ib), applied to the inputs as they are read from LDS
+template <int D, bool SN>
+__global__ __launch_bounds__(WN_NTH, 1) void wino_conv7_kernel(ConvGemmArgs a, int wg_per_unit, int n_tiles) {
+    constexpr int XW = WinoGeom<D>::XW, XP = WinoGeom<D>::XP, XBUF = WinoGeom<D>::XBUF, xw4 = XW / 4;
+    // ONE LDS array (a second object beside LDS-DMA staging makes hipcc wait vmcnt(0) before every ds_read)
+    extern __shared__ __attribute__((aligned(16))) float smem_all[];
+    float *Pm = smem_all;                                   // [4][64] per-row parameters (device_common.h)
+    float *Sp = smem_all + 4 * WN_BN;                       // [Cin][2] SnakeBeta parameters of the input channels (SN)
+    float *Xs = Sp + (SN ? 2 * a.Cin : 0);                  // [2][XBUF]: raw activation window, rows of XW floats
+    float *Ws = Xs + 2 * XBUF;                              // [2][8][16][64]
+
+    int nwg = gridDim.x, orig = blockIdx.x;                 // XCD-aware remap, as conv_gemm_kernel
+    int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+    int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    const int nt = id % n_tiles;
+    const int pt = id / n_tiles;
+    const int unit = pt / wg_per_unit;
+    const int T0 = (pt - unit * wg_per_unit) * WN_NT;
+    const int n0 = nt * WN_BN;
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const float *xu = a.x + (long)unit * a.x_us;
+    const int CinP = ((a.Cin + 31) / 32) * 32;
+    const int ncb = a.Cin / WN_BK;
+
+    // window of raw activations this workgroup needs: positions [pwin0, pwin0 + XW)
+    const int p0 = 2 * D * (T0 / D) + T0 % D;
+    const int pwin0 = (p0 - 6 * D) & ~3;                    // (floor to a multiple of 4, also when negative)
+    // this lane's tile: outputs p and p + D from the inputs p - 6D + i D, i = 0..7
+    const int T = T0 + wave * 32 + l31;
+    const int tq = T / D, tph = T - tq * D;
+    const int p = 2 * D * tq + tph;
+    const int xoff = p - 6 * D - pwin0;                     // >= 0; xoff + 7 D < XW
+    // which of the eight inputs exist (causal zero padding on the left, the end of the unit on the right): the window is
+    // fetched from clamped addresses, what must read as zero is zeroed here
+    unsigned dmask = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int pi = p + (i - 6) * D;
+        dmask |= (pi >= 0 && pi < a.Lin) ? (1u << i) : 0u;
+    }
+
+    // ---- parameter tables: ordinary loads, all BEFORE the first LDS-DMA (hipcc drains every DMA in flight at the next
+    // use of an ordinary load's result)
+    fill_param_table<WN_BN, false>(a, Pm, n0, tid, WN_NTH);
+    if constexpr (SN) {
+        for (int c = tid; c < a.Cin; c += WN_NTH) {
+            Sp[2 * c] = a.sn_a[c];
+            Sp[2 * c + 1] = a.sn_ib[c];
+        }
+    }
+
+    f32x16 acc[WN_PTS][2];
+#pragma unroll
+    for (int k = 0; k < WN_PTS; k++)
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[k][i][r] = 0.0f;
+
+    // ---- staging: global -> LDS directly (global_load_lds_dwordx4: no registers, no commit pass).  The LDS image of one
+    // wave-instruction is lane-linear (64 x 16 B), so piece j of the window is float4 index 256 j + tid of the [16][XW]
+    // image and its per-lane SOURCE address does the row / clamp arithmetic; weight tile k is a plain copy.
+    const int xlim = ((a.Lin + 3) & ~3) - 4;
+    unsigned xo[XP];
+#pragma unroll
+    for (int j = 0; j < XP; j++) {
+        const int i = tid + WN_NTH * j;
+        int row = i / xw4;
+        const int c4 = i - row * xw4;
+        row = row < WN_BK ? row : 0;                         // pieces past the window land in the buffer's padding
+        int pos = pwin0 + 4 * c4;
+        pos = pos < 0 ? 0 : (pos > xlim ? xlim : pos);
+        xo[j] = (unsigned)row * (unsigned)a.x_cs + (unsigned)pos;
+    }
+    const unsigned wo = (unsigned)(tid >> 4) * (unsigned)a.NP + (unsigned)(tid & 15) * 4u;
+    auto stage = [&](int cb, int buf) {
+        const float *xb = xu + (long)cb * WN_BK * a.x_cs;
+        float *xd = Xs + buf * XBUF + wave * 256;
+#pragma unroll
+        for (int j = 0; j < XP; j++)
+            __builtin_amdgcn_global_load_lds((wn_gptr_t)(xb + xo[j]), (wn_lptr_t)(xd + j * (WN_NTH * 4)), 16, 0, 0);
+        const float *wb = a.ww + ((long)cb * WN_BK) * a.NP + n0 + wo;
+        float *wd = Ws + buf * WN_WBUF + wave * 256;
+#pragma unroll
+        for (int k = 0; k < WN_PTS; k++)
+            __builtin_amdgcn_global_load_lds((wn_gptr_t)(wb + (long)k * CinP * a.NP), (wn_lptr_t)(wd + k * (WN_BK * WN_BN)), 16, 0, 0);
+    };
+
+    __syncthreads();                                         // tables written (no DMA in flight yet)
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int cb = 0; cb < ncb; cb++) {
+        const int buf = cb & 1;
+        if (cb + 1 < ncb) stage(cb + 1, buf ^ 1);            // lands during this block's MFMAs; the other buffer has no readers
+        {
+            const float *xs = Xs + buf * XBUF + xoff;
+            const float *ws = Ws + buf * WN_WBUF + l31;
+            const float *sp = Sp + 2 * (cb * WN_BK + h);
+            float dv[3][8], vv[2][WN_PTS], av[2][WN_PTS][2];
+            float2 sv[3];
+            auto load_d = [&](int kk, int sl) {
+                const float *xk = xs + (2 * kk + h) * XW;
+#pragma unroll
+                for (int i = 0; i < 8; i++) dv[sl][i] = xk[i * D];
+                if constexpr (SN) sv[sl] = *reinterpret_cast<const float2 *>(sp + 4 * kk);
+            };
+            auto load_a = [&](int kk, int sl) {
+                const float *wk = ws + (2 * kk + h) * WN_BN;
+#pragma unroll
+                for (int q = 0; q < WN_PTS; q++) {
+                    av[sl][q][0] = wk[q * (WN_BK * WN_BN)];
+                    av[sl][q][1] = wk[q * (WN_BK * WN_BN) + 32];
+                }
+            };
+            // zero padding, SnakeBeta (snake(0) == 0 keeps the padding), then V = B^T d for the points 0, 1, -1, 2, -2, 1/2, -1/2, inf
+            auto transform = [&](int ds, int vs) {
+                float d[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) d[i] = (dmask >> i) & 1u ? dv[ds][i] : 0.0f;
+                if constexpr (SN) {
+                    const f32x2 ea = (f32x2)(sv[ds].x), ib = (f32x2)(sv[ds].y);
+#pragma unroll
+                    for (int i = 0; i < 8; i += 2) {
+                        const f32x2 r = snake_beta2(mk2(d[i], d[i + 1]), ea, ib);
+                        d[i] = r.x;
+                        d[i + 1] = r.y;
+                    }
+                }
+                const float d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3], d4 = d[4], d5 = d[5], d6 = d[6], d7 = d[7];
+                const float e12 = fmaf(-4.25f, d4, d2) + d6, o12 = fmaf(-4.25f, d3, d1) + d5;
+                const float e34 = fmaf(0.25f, d2, fmaf(-1.25f, d4, d6)), o34 = fmaf(0.5f, d1, fmaf(-2.5f, d3, 2.0f * d5));
+                const float e56 = fmaf(4.0f, d2, fmaf(-5.0f, d4, d6)), o56 = fmaf(2.0f, d1, fmaf(-2.5f, d3, 0.5f * d5));
+                vv[vs][0] = fmaf(5.25f, d4 - d2, d0 - d6);
+                vv[vs][1] = e12 + o12;
+                vv[vs][2] = e12 - o12;
+                vv[vs][3] = e34 + o34;
+                vv[vs][4] = e34 - o34;
+                vv[vs][5] = e56 + o56;
+                vv[vs][6] = e56 - o56;
+                vv[vs][7] = fmaf(5.25f, d3 - d5, d7 - d1);
+            };
+            // One wave per SIMD: only this wave's own instruction stream hides latency.  Three-deep pipeline over the eight
+            // k-pairs of the block: step kk issues the input reads of step kk+2 and the weight reads of step kk+1,
+            // transforms the inputs of step kk+1, and feeds the matrix cores with step kk -- three independent streams
+            // that sched_group_barrier interleaves around the MFMAs.
+            load_d(0, 0);
+            load_a(0, 0);
+            load_d(1, 1);
+            transform(0, 0);
+#pragma unroll
+            for (int kk = 0; kk < WN_BK / 2; kk++) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk + 2 < WN_BK / 2) load_d(kk + 2, (kk + 2) % 3);
+                if (kk + 1 < WN_BK / 2) {
+                    load_a(kk + 1, (kk + 1) & 1);
+                    transform((kk + 1) % 3, (kk + 1) & 1);
+                }
+#pragma unroll
+                for (int q = 0; q < WN_PTS; q++) {
+                    acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk & 1][q][0], vv[kk & 1][q], acc[q][0], 0, 0, 0);
+                    acc[q][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk & 1][q][1], vv[kk & 1][q], acc[q][1], 0, 0, 0);
+                }
+#pragma unroll
+                for (int g = 0; g < 16; g++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one LDS read
+                    __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);      // VALU in its shadow
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // the next block's DMA has had this whole block to land; every wave is done reading this block's buffers
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+
+    // ---- output transform  y = A^T M  and epilogue: bias, optional SnakeBeta of the consumer, store
+    //   y0 = M0 + M1 + M2 + M3 + M4 + M5 + M6
+    //   y1 = M1 - M2 + 2 (M3 - M4) + (M5 - M6) / 2 + M7
+    float *yu = a.y + (long)unit * a.y_us;
+    const bool ok0 = p < a.M, ok1 = p + D < a.M;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            float y0[2], y1[2];
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const float m0 = acc[0][i][r + e], m1 = acc[1][i][r + e], m2 = acc[2][i][r + e], m3 = acc[3][i][r + e],
+                            m4 = acc[4][i][r + e], m5 = acc[5][i][r + e], m6 = acc[6][i][r + e], m7 = acc[7][i][r + e];
+                y0[e] = ((m1 + m2) + (m3 + m4)) + ((m5 + m6) + m0);
+                y1[e] = fmaf(2.0f, m3 - m4, m1 - m2) + fmaf(0.5f, m5 - m6, m7);
+            }
+            const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;          // rows row, row + 1
+            f32x2 b = mk2(Pm[row], Pm[row + 1]);
+            f32x2 o0 = mk2(y0[0], y0[1]), o1 = mk2(y1[0], y1[1]);
+            if (a.bias) { o0 = o0 + b; o1 = o1 + b; }
+            if (a.psn_a) {
+                const f32x2 pa = mk2(Pm[2 * WN_BN + row], Pm[2 * WN_BN + row + 1]), pb = mk2(Pm[3 * WN_BN + row], Pm[3 * WN_BN + row + 1]);
+                o0 = snake_beta2(o0, pa, pb);
+                o1 = snake_beta2(o1, pa, pb);
+            }
+            float *yr = yu + (long)(n0 + row) * a.y_cs + p;
+            if (ok0) { yr[0] = o0.x; yr[a.y_cs] = o0.y; }
+            if (ok1) { yr[D] = o1.x; yr[a.y_cs + D] = o1.y; }
+        }
+    }
+}
+
+bool wino_selected(const ConvGemmArgs &a) {
+    if (!a.ww || a.wb || a.w2) return false;
+    const int d = a.shift_step;
+    return a.ntaps == 7 && a.S == 1 && (d == 1 || d == 3 || d == 9) && a.shift0 == -6 * d && a.units >= 1 && a.N == a.NP &&
+           a.N % WN_BN == 0 && a.Cin % WN_BK == 0 && !a.res && !a.rscale && !a.y2 && !a.xb && !a.yb && a.act == ACT_NONE && !a.in_elu &&
+           a.s2d <= 1 && a.M == a.Lin && a.y;
+}
+
+const char *wino_kernel_name(const ConvGemmArgs &a) {      // as rocprofv3 prints it
+    if (a.sn_a) return a.shift_step == 1 ? "wino_conv7_kernel<1,true>" : a.shift_step == 3 ? "wino_conv7_kernel<3,true>" : "wino_conv7_kernel<9,true>";
+    return a.shift_step == 1 ? "wino_conv7_kernel<1,false>" : a.shift_step == 3 ? "wino_conv7_kernel<3,false>" : "wino_conv7_kernel<9,false>";
+}
+
+template <int D, bool SN>
+static hipError_t wino_launch_one(const ConvGemmArgs &a, hipStream_t s) {
+    // tiles of a unit: the pairs (p, p + D) with floor(p / D) even and p < M
+    const int n_pairs = (a.M + 2 * D - 1) / (2 * D) * D;
+    const int wg_per_unit = (n_pairs + WN_NT - 1) / WN_NT;
+    const int n_tiles = a.N / WN_BN;
+    const long grid = (long)wg_per_unit * a.units * n_tiles;
+    if (grid > 0x7fffffffL) return hipErrorInvalidValue;
+    // Window bound: a workgroup's tiles T0 .. T0+127 have base positions within 2D (127/D + 1) + D - 1 <= 253 + 3D of the
+    // first one, the window starts at most 6D + 3 before it and the last read is D past the base: XW >= 257 + 10 D.
+    const size_t lds = sizeof(float) * (4 * WN_BN + (SN ? 2 * (size_t)a.Cin : 0) + 2 * (size_t)WinoGeom<D>::XBUF + 2 * (size_t)WN_WBUF);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    static bool done[64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64 && !done[dev]) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(wino_conv7_kernel<D, SN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        done[dev] = true;
+    }
+    hipLaunchKernelGGL((wino_conv7_kernel<D, SN>), dim3((unsigned)grid), dim3(WN_NTH), lds, s, a, wg_per_unit, n_tiles);
+    return hipGetLastError();
+}
+
+hipError_t launch_wino_conv7(const ConvGemmArgs &a, hipStream_t s) {
+    if (!wino_selected(a)) return hipErrorInvalidValue;
+    if (a.M <= 0) return hipSuccess;
+    // host-side shape checks: what the kernel's 16-byte accesses assume
+    if ((a.x_cs & 3) || (a.x_us & 3) || ((uintptr_t)a.x & 15) || ((uintptr_t)a.ww & 15) || (a.NP & 3) || a.Lin < 1 ||
+        (a.sn_a && !a.sn_ib) || a.Cin > 4096)
+        return hipErrorInvalidValue;
+    const bool sn = a.sn_a != nullptr;
+    switch (a.shift_step) {
+        case 1: return sn ? wino_launch_one<1, true>(a, s) : wino_launch_one<1, false>(a, s);
+        case 3: return sn ? wino_launch_one<3, true>(a, s) : wino_launch_one<3, false>(a, s);
+        default: return sn ? wino_launch_one<9, true>(a, s) : wino_launch_one<9, false>(a, s);
+    }
+}
+
+}  // namespace hipvoc
