@@ -324,6 +324,7 @@ def main(argv=None):
 
     # ---------------------------------------------------------------- roofline of the dominant kernel: one profiled pass
     roofline = None
+    by_kernel = []
     kernels = {}
     if rank == 0 and not stub:
         voc.set_profile(True)
@@ -338,17 +339,30 @@ def main(argv=None):
             k["ms"] += ms
             k["flops"] += flops
             k["launches"] += launches
-        dom = max(kernels, key=lambda n: kernels[n]["ms"])
-        kd = kernels[dom]
-        achieved = kd["flops"] / (kd["ms"] * 1e-3) / 1e12
-        traffic, traffic_src = pmc_traffic(dom, G)
         # bf16x3: three bf16 MFMAs per algorithmic product, so the roof of the ALGORITHMIC rate is a third of the bf16 peak
         peak = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "bf16x3": round(PEAK_BF16_MFMA_TFLOPS / 3, 1)}[args.dtype]
-        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 3), "peak": peak,
-                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
-                    "traffic_source": traffic_src,
-                    "avg_launch_ms": round(kd["ms"] / kd["launches"], 4), "launches_per_pass": kd["launches"],
-                    "units_per_pass": G, "share_of_pass_time": round(kd["ms"] / sum(k["ms"] for k in kernels.values()), 3)}
+        total_ms = sum(k["ms"] for k in kernels.values())
+
+        def roof(name):
+            kd = kernels[name]
+            achieved = kd["flops"] / (kd["ms"] * 1e-3) / 1e12
+            traffic, traffic_src = pmc_traffic(name, G)
+            r = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
+                 "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+                 "avg_launch_ms": round(kd["ms"] / kd["launches"], 4), "launches_per_pass": kd["launches"],
+                 "units_per_pass": G, "share_of_pass_time": round(kd["ms"] / total_ms, 3)}
+            if name.startswith("wino_conv7_kernel"):
+                # Winograd F(2,7): 8 multiplications where the direct form (what the algorithmic count assumes) has 14, so
+                # `achieved` can exceed the MFMA peak; the matrix cores execute 4/7 of it
+                r["executed_mfma_tflops"] = round(achieved * 4 / 7, 3)
+                r["executed_frac"] = round(achieved * 4 / 7 / peak, 4)
+                r["note"] = ("achieved = algorithmic (direct-form) FLOPs / time; the kernel is a Winograd F(2,7) convolution that "
+                             "executes 4/7 of those multiplications on the matrix cores (executed_*)")
+            return r
+
+        dom = max(kernels, key=lambda n: kernels[n]["ms"])
+        roofline = roof(dom)
+        by_kernel = [roof(n) for n in sorted(kernels, key=lambda n: -kernels[n]["ms"]) if kernels[n]["ms"] / total_ms >= 0.03 and kernels[n]["flops"] > 0]
 
     # ---------------------------------------------------------------- HBM-bound kernels: algorithmic bytes / live time
     hbm = {}
@@ -437,7 +451,7 @@ def main(argv=None):
             "host_to_host_over_value": None if h2h is None else round(h2h / value, 4),
             "single_utterance_latency_ms": None if lat_ms is None else round(lat_ms, 2),
             "stitching": stitching,
-            "roofline": roofline, "cpu_baseline": cpu, "parity_vs_oracle": parity, "hbm_bound_kernels": hbm,
+            "roofline": roofline, "roofline_by_kernel": by_kernel, "cpu_baseline": cpu, "parity_vs_oracle": parity, "hbm_bound_kernels": hbm,
             "kernels": {k: {"ms_per_pass": round(v["ms"], 3), "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2),
                             "launches": v["launches"]} for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])},
         }

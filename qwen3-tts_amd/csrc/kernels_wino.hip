@@ -32,15 +32,18 @@ namespace hipvoc {
 
 static constexpr int WN_BK = 16;      // input channels per K stage
 static constexpr int WN_NT = 128;     // tiles per workgroup (4 waves x 32)
-static constexpr int WN_NTH = 256;
 static constexpr int WN_BN = 64;      // output channels per workgroup (2 row tiles)
 static constexpr int WN_PTS = 8;
 
-template <int D>
+// RT = row tiles (32 output channels each) per wave: 2 -> 4 waves per workgroup, one wave per SIMD (256 accumulator
+// registers); 1 -> 8 waves, two per SIMD: waves w and w + 4 own the same tiles and one row tile each.
+template <int D, int RT>
 struct WinoGeom {
+    static constexpr int NTH = RT == 2 ? 256 : 512;
     static constexpr int XW = (257 + 10 * D + 3) & ~3;                    // raw window: see the bound in launch_wino_conv7
-    static constexpr int XP = (WN_BK * (XW / 4) + WN_NTH - 1) / WN_NTH;   // LDS-DMA pieces (16 B per lane) of the window per thread
-    static constexpr int XBUF = XP * WN_NTH * 4;                          // floats per window buffer (whole pieces: the tail is padding)
+    static constexpr int XP = (WN_BK * (XW / 4) + NTH - 1) / NTH;         // LDS-DMA pieces (16 B per lane) of the window per thread
+    static constexpr int XBUF = XP * NTH * 4;                             // floats per window buffer (whole pieces: the tail is padding)
+    static constexpr int WP = WN_PTS * WN_BK * WN_BN / 4 / NTH;           // pieces of the weight tiles per thread
 };
 static constexpr int WN_WBUF = WN_PTS * WN_BK * WN_BN;                    // floats per weight buffer
 
@@ -48,9 +51,10 @@ typedef __attribute__((address_space(1))) const void *wn_gptr_t;
 typedef __attribute__((address_space(3))) void *wn_lptr_t;
 
 // SN: the conv has a SnakeBeta prologue (a.sn_a / a.sn_ib), applied to the inputs as they are read from LDS
-template <int D, bool SN>
-__global__ __launch_bounds__(WN_NTH, 1) void wino_conv7_kernel(ConvGemmArgs a, int wg_per_unit, int n_tiles) {
-    constexpr int XW = WinoGeom<D>::XW, XP = WinoGeom<D>::XP, XBUF = WinoGeom<D>::XBUF, xw4 = XW / 4;
+template <int D, bool SN, int RT>
+__global__ __launch_bounds__((WinoGeom<D, RT>::NTH), 1) void wino_conv7_kernel(ConvGemmArgs a, int wg_per_unit, int n_tiles) {
+    using GEO = WinoGeom<D, RT>;
+    constexpr int NTH = GEO::NTH, XW = GEO::XW, XP = GEO::XP, XBUF = GEO::XBUF, WP = GEO::WP, xw4 = XW / 4;
     // ONE LDS array (a second object beside LDS-DMA staging makes hipcc wait vmcnt(0) before every ds_read)
     extern __shared__ __attribute__((aligned(16))) float smem_all[];
     float *Pm = smem_all;                                   // [4][64] per-row parameters (device_common.h)
@@ -77,7 +81,8 @@ __global__ __launch_bounds__(WN_NTH, 1) void wino_conv7_kernel(ConvGemmArgs a, i
     const int p0 = 2 * D * (T0 / D) + T0 % D;
     const int pwin0 = (p0 - 6 * D) & ~3;                    // (floor to a multiple of 4, also when negative)
     // this lane's tile: outputs p and p + D from the inputs p - 6D + i D, i = 0..7
-    const int T = T0 + wave * 32 + l31;
+    const int tw = wave & 3, rh = RT == 2 ? 0 : wave >> 2;      // tile group of this wave, its row tile (RT == 1)
+    const int T = T0 + tw * 32 + l31;
     const int tq = T / D, tph = T - tq * D;
     const int p = 2 * D * tq + tph;
     const int xoff = p - 6 * D - pwin0;                     // >= 0; xoff + 7 D < XW
@@ -92,19 +97,19 @@ __global__ __launch_bounds__(WN_NTH, 1) void wino_conv7_kernel(ConvGemmArgs a, i
 
     // ---- parameter tables: ordinary loads, all BEFORE the first LDS-DMA (hipcc drains every DMA in flight at the next
     // use of an ordinary load's result)
-    fill_param_table<WN_BN, false>(a, Pm, n0, tid, WN_NTH);
+    fill_param_table<WN_BN, false>(a, Pm, n0, tid, NTH);
     if constexpr (SN) {
-        for (int c = tid; c < a.Cin; c += WN_NTH) {
+        for (int c = tid; c < a.Cin; c += NTH) {
             Sp[2 * c] = a.sn_a[c];
             Sp[2 * c + 1] = a.sn_ib[c];
         }
     }
 
-    f32x16 acc[WN_PTS][2];
+    f32x16 acc[WN_PTS][RT];
 #pragma unroll
     for (int k = 0; k < WN_PTS; k++)
 #pragma unroll
-        for (int i = 0; i < 2; i++)
+        for (int i = 0; i < RT; i++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[k][i][r] = 0.0f;
 
@@ -115,7 +120,7 @@ __global__ __launch_bounds__(WN_NTH, 1) void wino_conv7_kernel(ConvGemmArgs a, i
     unsigned xo[XP];
 #pragma unroll
     for (int j = 0; j < XP; j++) {
-        const int i = tid + WN_NTH * j;
+        const int i = tid + NTH * j;
         int row = i / xw4;
         const int c4 = i - row * xw4;
         row = row < WN_BK ? row : 0;                         // pieces past the window land in the buffer's padding
@@ -123,18 +128,24 @@ __global__ __launch_bounds__(WN_NTH, 1) void wino_conv7_kernel(ConvGemmArgs a, i
         pos = pos < 0 ? 0 : (pos > xlim ? xlim : pos);
         xo[j] = (unsigned)row * (unsigned)a.x_cs + (unsigned)pos;
     }
-    const unsigned wo = (unsigned)(tid >> 4) * (unsigned)a.NP + (unsigned)(tid & 15) * 4u;
+    // weight piece k of this thread: float4 index tid + NTH k of the [8][16][64] image = (point, row, float4 column)
+    unsigned wo[WP];
+#pragma unroll
+    for (int k = 0; k < WP; k++) {
+        const int i = tid + NTH * k, q = i >> 8, r = (i >> 4) & 15, c4 = i & 15;
+        wo[k] = ((unsigned)q * (unsigned)CinP + (unsigned)r) * (unsigned)a.NP + (unsigned)c4 * 4u;
+    }
     auto stage = [&](int cb, int buf) {
         const float *xb = xu + (long)cb * WN_BK * a.x_cs;
         float *xd = Xs + buf * XBUF + wave * 256;
 #pragma unroll
         for (int j = 0; j < XP; j++)
-            __builtin_amdgcn_global_load_lds((wn_gptr_t)(xb + xo[j]), (wn_lptr_t)(xd + j * (WN_NTH * 4)), 16, 0, 0);
-        const float *wb = a.ww + ((long)cb * WN_BK) * a.NP + n0 + wo;
+            __builtin_amdgcn_global_load_lds((wn_gptr_t)(xb + xo[j]), (wn_lptr_t)(xd + j * (NTH * 4)), 16, 0, 0);
+        const float *wb = a.ww + ((long)cb * WN_BK) * a.NP + n0;
         float *wd = Ws + buf * WN_WBUF + wave * 256;
 #pragma unroll
-        for (int k = 0; k < WN_PTS; k++)
-            __builtin_amdgcn_global_load_lds((wn_gptr_t)(wb + (long)k * CinP * a.NP), (wn_lptr_t)(wd + k * (WN_BK * WN_BN)), 16, 0, 0);
+        for (int k = 0; k < WP; k++)
+            __builtin_amdgcn_global_load_lds((wn_gptr_t)(wb + wo[k]), (wn_lptr_t)(wd + k * (NTH * 4)), 16, 0, 0);
     };
 
     __syncthreads();                                         // tables written (no DMA in flight yet)
@@ -145,9 +156,9 @@ __global__ __launch_bounds__(WN_NTH, 1) void wino_conv7_kernel(ConvGemmArgs a, i
         if (cb + 1 < ncb) stage(cb + 1, buf ^ 1);            // lands during this block's MFMAs; the other buffer has no readers
         {
             const float *xs = Xs + buf * XBUF + xoff;
-            const float *ws = Ws + buf * WN_WBUF + l31;
+            const float *ws = Ws + buf * WN_WBUF + l31 + rh * 32;
             const float *sp = Sp + 2 * (cb * WN_BK + h);
-            float dv[3][8], vv[2][WN_PTS], av[2][WN_PTS][2];
+            float dv[3][8], vv[2][WN_PTS], av[2][WN_PTS][RT];
             float2 sv[3];
             auto load_d = [&](int kk, int sl) {
                 const float *xk = xs + (2 * kk + h) * XW;
@@ -158,10 +169,9 @@ __global__ __launch_bounds__(WN_NTH, 1) void wino_conv7_kernel(ConvGemmArgs a, i
             auto load_a = [&](int kk, int sl) {
                 const float *wk = ws + (2 * kk + h) * WN_BN;
 #pragma unroll
-                for (int q = 0; q < WN_PTS; q++) {
-                    av[sl][q][0] = wk[q * (WN_BK * WN_BN)];
-                    av[sl][q][1] = wk[q * (WN_BK * WN_BN) + 32];
-                }
+                for (int q = 0; q < WN_PTS; q++)
+#pragma unroll
+                    for (int i = 0; i < RT; i++) av[sl][q][i] = wk[q * (WN_BK * WN_BN) + 32 * i];
             };
             // zero padding, SnakeBeta (snake(0) == 0 keeps the padding), then V = B^T d for the points 0, 1, -1, 2, -2, 1/2, -1/2, inf
             auto transform = [&](int ds, int vs) {
@@ -207,15 +217,24 @@ __global__ __launch_bounds__(WN_NTH, 1) void wino_conv7_kernel(ConvGemmArgs a, i
                     transform((kk + 1) % 3, (kk + 1) & 1);
                 }
 #pragma unroll
-                for (int q = 0; q < WN_PTS; q++) {
-                    acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk & 1][q][0], vv[kk & 1][q], acc[q][0], 0, 0, 0);
-                    acc[q][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk & 1][q][1], vv[kk & 1][q], acc[q][1], 0, 0, 0);
-                }
+                for (int q = 0; q < WN_PTS; q++)
 #pragma unroll
-                for (int g = 0; g < 16; g++) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one LDS read
-                    __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);      // VALU in its shadow
+                    for (int i = 0; i < RT; i++)
+                        acc[q][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk & 1][q][i], vv[kk & 1][q], acc[q][i], 0, 0, 0);
+                if constexpr (RT == 2) {
+#pragma unroll
+                    for (int g = 0; g < 16; g++) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one LDS read
+                        __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);      // VALU in its shadow
+                    }
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 8; g++) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -230,7 +249,7 @@ __global__ __launch_bounds__(WN_NTH, 1) void wino_conv7_kernel(ConvGemmArgs a, i
     float *yu = a.y + (long)unit * a.y_us;
     const bool ok0 = p < a.M, ok1 = p + D < a.M;
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < RT; i++) {
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
             float y0[2], y1[2];
@@ -241,7 +260,7 @@ __global__ __launch_bounds__(WN_NTH, 1) void wino_conv7_kernel(ConvGemmArgs a, i
                 y0[e] = ((m1 + m2) + (m3 + m4)) + ((m5 + m6) + m0);
                 y1[e] = fmaf(2.0f, m3 - m4, m1 - m2) + fmaf(0.5f, m5 - m6, m7);
             }
-            const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;          // rows row, row + 1
+            const int row = (i + rh) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;   // rows row, row + 1
             f32x2 b = mk2(Pm[row], Pm[row + 1]);
             f32x2 o0 = mk2(y0[0], y0[1]), o1 = mk2(y1[0], y1[1]);
             if (a.bias) { o0 = o0 + b; o1 = o1 + b; }
@@ -265,13 +284,26 @@ bool wino_selected(const ConvGemmArgs &a) {
            a.s2d <= 1 && a.M == a.Lin && a.y;
 }
 
+static int wino_rt();
 const char *wino_kernel_name(const ConvGemmArgs &a) {      // as rocprofv3 prints it
-    if (a.sn_a) return a.shift_step == 1 ? "wino_conv7_kernel<1,true>" : a.shift_step == 3 ? "wino_conv7_kernel<3,true>" : "wino_conv7_kernel<9,true>";
-    return a.shift_step == 1 ? "wino_conv7_kernel<1,false>" : a.shift_step == 3 ? "wino_conv7_kernel<3,false>" : "wino_conv7_kernel<9,false>";
+    static char names[2][3][2][40];
+    const int di = a.shift_step == 1 ? 0 : a.shift_step == 3 ? 1 : 2, sn = a.sn_a ? 1 : 0, rt = wino_rt();
+    char *n = names[sn][di][rt - 1];
+    if (!n[0]) snprintf(n, 40, "wino_conv7_kernel<%d,%s,%d>", a.shift_step, sn ? "true" : "false", rt);
+    return n;
 }
 
-template <int D, bool SN>
+// HIPVOC_WINO_RT: row tiles per wave.  Default 1 (8 waves, two per SIMD: the second wave fills part of the first one's
+// per-block prologue and barrier wait; 142.9 ms per 64-unit pass against 145.3 with 2 = one wave per SIMD).
+static int wino_rt() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("HIPVOC_WINO_RT"); v = e && atoi(e) == 2 ? 2 : 1; }
+    return v;
+}
+
+template <int D, bool SN, int RT>
 static hipError_t wino_launch_one(const ConvGemmArgs &a, hipStream_t s) {
+    using GEO = WinoGeom<D, RT>;
     // tiles of a unit: the pairs (p, p + D) with floor(p / D) even and p < M
     const int n_pairs = (a.M + 2 * D - 1) / (2 * D) * D;
     const int wg_per_unit = (n_pairs + WN_NT - 1) / WN_NT;
@@ -280,18 +312,18 @@ static hipError_t wino_launch_one(const ConvGemmArgs &a, hipStream_t s) {
     if (grid > 0x7fffffffL) return hipErrorInvalidValue;
     // Window bound: a workgroup's tiles T0 .. T0+127 have base positions within 2D (127/D + 1) + D - 1 <= 253 + 3D of the
     // first one, the window starts at most 6D + 3 before it and the last read is D past the base: XW >= 257 + 10 D.
-    const size_t lds = sizeof(float) * (4 * WN_BN + (SN ? 2 * (size_t)a.Cin : 0) + 2 * (size_t)WinoGeom<D>::XBUF + 2 * (size_t)WN_WBUF);
+    const size_t lds = sizeof(float) * (4 * WN_BN + (SN ? 2 * (size_t)a.Cin : 0) + 2 * (size_t)GEO::XBUF + 2 * (size_t)WN_WBUF);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     static bool done[64] = {};
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 64 && !done[dev]) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(wino_conv7_kernel<D, SN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(wino_conv7_kernel<D, SN, RT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         done[dev] = true;
     }
-    hipLaunchKernelGGL((wino_conv7_kernel<D, SN>), dim3((unsigned)grid), dim3(WN_NTH), lds, s, a, wg_per_unit, n_tiles);
+    hipLaunchKernelGGL((wino_conv7_kernel<D, SN, RT>), dim3((unsigned)grid), dim3(GEO::NTH), lds, s, a, wg_per_unit, n_tiles);
     return hipGetLastError();
 }
 
@@ -303,11 +335,14 @@ hipError_t launch_wino_conv7(const ConvGemmArgs &a, hipStream_t s) {
         (a.sn_a && !a.sn_ib) || a.Cin > 4096)
         return hipErrorInvalidValue;
     const bool sn = a.sn_a != nullptr;
+#define WN_GO(D_) (sn ? (wino_rt() == 1 ? wino_launch_one<D_, true, 1>(a, s) : wino_launch_one<D_, true, 2>(a, s)) \
+                      : (wino_rt() == 1 ? wino_launch_one<D_, false, 1>(a, s) : wino_launch_one<D_, false, 2>(a, s)))
     switch (a.shift_step) {
-        case 1: return sn ? wino_launch_one<1, true>(a, s) : wino_launch_one<1, false>(a, s);
-        case 3: return sn ? wino_launch_one<3, true>(a, s) : wino_launch_one<3, false>(a, s);
-        default: return sn ? wino_launch_one<9, true>(a, s) : wino_launch_one<9, false>(a, s);
+        case 1: return WN_GO(1);
+        case 3: return WN_GO(3);
+        default: return WN_GO(9);
     }
+#undef WN_GO
 }
 
 }  // namespace hipvoc
