@@ -125,6 +125,7 @@ struct Ctx {
     bool post_snake = true;
     bool phase_major = true;   // transposed-conv rows phase-major (HIPVOC_PHASE_MAJOR=0: channel-major)
     bool packed = true;        // bf16 mode: GEMM-to-GEMM tensors of the decoder stack exchanged as packed bf16 (HIPVOC_PACKED=0: fp32)
+    bool wino_tconv = true;    // fp32 mode: the decoder blocks' transposed convs by F(3,2) (HIPVOC_WINO_TCONV=0: direct)
     bool wino_unfuse = true;   // blocks whose residual units could be fused run un-fused when their conv7 has a Winograd form (HIPVOC_WINO_UNFUSE=0)
     bool wino = true;          // fp32 mode: k = 7 convs of the un-fused residual units by Winograd F(2,7) (HIPVOC_WINO=0: direct)
     bool trim_right = false;   // trans-conv trim policy (metadata transconv_trim_right_only=1): keep L*r samples instead of (L-1)*r
@@ -465,6 +466,9 @@ struct Loader {
         // mode: 8-byte stores into the packed tensors instead of four 2-byte ones; both modes: one integer division
         // per half tile in the epilogue instead of one per row)
         g.pm = c->phase_major && s > 1 && Co % 8 == 0;
+        // fp32 with the Winograd trans-conv kernel: channel-major rows, so that one workgroup writes every phase of its
+        // channels (whole cache lines leave the workgroup, not one phase's every s-th float)
+        if (c->wino && c->wino_tconv && !c->bf16) g.pm = 0;
         int CinP = rup(Cin, 32);
         std::vector<float> p((size_t)g.ntaps * CinP * g.NP, 0.0f);
         for (int ci = 0; ci < Cin; ci++)
@@ -479,6 +483,20 @@ struct Loader {
                     }
                 }
         finish(g, p, CinP);
+        // F(3,2) form of the decoder blocks' transposed convs (fp32; kernels_wino.hip): U = (g0, (g0 + g1)/2, (g0 - g1)/2, g1)
+        // with g0 / g1 the two tap planes above
+        if (c->wino && c->wino_tconv && !c->bf16 && K == 2 * s && g.N == g.NP && (g.N % 128 == 0 || g.N % 96 == 0) && Cin % 16 == 0) {
+            const size_t plane = (size_t)CinP * g.NP;
+            std::vector<float> u(4 * plane);
+            for (size_t e = 0; e < plane; e++) {
+                const double g0 = p[e], g1 = p[plane + e];
+                u[e] = (float)g0;
+                u[plane + e] = (float)(0.5 * (g0 + g1));
+                u[2 * plane + e] = (float)(0.5 * (g0 - g1));
+                u[3 * plane + e] = (float)g1;
+            }
+            g.ww = upload(u);
+        }
         if (!bias_name.empty()) g.bias = vec(bias_name, Co);
         return g;
     }
@@ -1371,6 +1389,7 @@ static void *load_impl(const char *weights_path, int device_id, int dtype, int u
     if (const char *ps = getenv("HIPVOC_PHASE_MAJOR")) c->phase_major = atoi(ps) != 0;
     if (const char *ps = getenv("HIPVOC_WINO")) c->wino = atoi(ps) != 0;
     if (const char *ps = getenv("HIPVOC_WINO_UNFUSE")) c->wino_unfuse = atoi(ps) != 0;
+    if (const char *ps = getenv("HIPVOC_WINO_TCONV")) c->wino_tconv = atoi(ps) != 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
     {   // this device's copy of the static scratch array of hipvoc_decode_units_device_noalloc (scratch.hip): resolved
         // here, once per device, with the device current

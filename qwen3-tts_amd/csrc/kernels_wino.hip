@@ -276,8 +276,248 @@ __global__ __launch_bounds__((WinoGeom<D, RT>::NTH), 1) void wino_conv7_kernel(C
     }
 }
 
+// -------------------------------------------------------------------------------------------------------------------------
+// The decoder blocks' transposed convs (kernel 2s, stride s) by F(3,2).  Per output phase r such a conv is a 2-tap filter
+// along the INPUT positions q:  y[co][q s + r] = g0 x[q + sh] + g1 x[q + sh + 1]  (g0 = W[..][r + s], g1 = W[..][r], rows
+// n = (co, r); sh = 0, or -1 with the right-only trim).  F(3,2) makes three consecutive q from four products,
+//     V = (d0 - d2, d1 + d2, d2 - d1, d3 - d1),   U = (g0, (g0 + g1)/2, (g0 - g1)/2, g1),
+//     y0 = M0 + M1 + M2,  y1 = M1 - M2,  y2 = M1 + M2 + M3,
+// so the matrix cores do 4/6 of the direct kernel's work; the constants are 1 and 1/2, the rounding is that of the direct
+// form to within a few ulp.  Same structure as wino_conv7_kernel: lane = tile (three q), LDS-DMA staging, one barrier per
+// block of 16 input channels, three-deep software pipeline.  Workgroup = RW wave-rows x 4 tile groups; a wave owns RT row
+// tiles of 32 rows x 32 tiles and 4 x RT accumulator tiles: (RT, RW) = (2, 2) -> 128 rows, 8 waves, two per SIMD; (1, 3) ->
+// 96 rows, 12 waves, three per SIMD (N = 288 of the last block, whose time goes into its stores).
+static constexpr int WT_PTS = 4;
+static constexpr int WT_XW = 3 * WN_NT + 8;           // window: positions 3 T0 + sh (floored to 4) .. + 3*128 + 3
+
+template <int RT, int RW>
+struct TconvGeom {
+    static constexpr int NTH = 4 * RW * 64;
+    static constexpr int BN = 32 * RT * RW;                                  // rows per workgroup
+    static constexpr int XP = (WN_BK * (WT_XW / 4) + NTH - 1) / NTH;
+    static constexpr int XBUF = XP * NTH * 4;
+    static constexpr int WF4 = WT_PTS * WN_BK * BN / 4;                      // float4 of the weight tiles of one block
+    static constexpr int WP = (WF4 + NTH - 1) / NTH;
+    static constexpr int WBUF = WP * NTH * 4;
+};
+
+template <bool SN, int RT, int RW>
+__global__ __launch_bounds__((TconvGeom<RT, RW>::NTH), 1) void wino_tconv_kernel(ConvGemmArgs a, int wg_per_unit, int n_tiles) {
+    using GEO = TconvGeom<RT, RW>;
+    constexpr int NTH = GEO::NTH, BN = GEO::BN, XW = WT_XW, XP = GEO::XP, XBUF = GEO::XBUF, WP = GEO::WP, WBUF = GEO::WBUF, xw4 = XW / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem_all[];
+    float *Pm = smem_all;                                   // [4][BN] per-row parameters: bias | - | psn_a | psn_ib
+    float *Sp = smem_all + 4 * BN;                          // [Cin][2] (SN)
+    float *Xs = Sp + (SN ? 2 * a.Cin : 0);                  // [2][XBUF]: rows of XW floats
+    float *Ws = Xs + 2 * XBUF;                              // [2][4][16][BN]
+
+    int nwg = gridDim.x, orig = blockIdx.x;                 // XCD-aware remap, as conv_gemm_kernel
+    int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+    int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    const int nt = id % n_tiles;
+    const int pt = id / n_tiles;
+    const int unit = pt / wg_per_unit;
+    const int T0 = (pt - unit * wg_per_unit) * WN_NT;
+    const int n0 = nt * BN;
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int tw = wave & 3, rw = wave >> 2;                // tile group, wave-row
+    const float *xu = a.x + (long)unit * a.x_us;
+    const int CinP = ((a.Cin + 31) / 32) * 32;
+    const int ncb = a.Cin / WN_BK;
+    const int sh = a.shift0;
+
+    const int pwin0 = (3 * T0 + sh) & ~3;                   // first position of the window (floor to 4, also when negative)
+    const int q0 = 3 * (T0 + tw * 32 + l31);                // this lane's tile: input steps q0, q0 + 1, q0 + 2
+    const int xoff = q0 + sh - pwin0;                       // inputs at xoff .. xoff + 3
+    unsigned dmask = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int pi = q0 + sh + i;
+        dmask |= (pi >= 0 && pi < a.Lin) ? (1u << i) : 0u;
+    }
+
+    fill_param_table<BN, false>(a, Pm, n0, tid, NTH);       // (ordinary loads: all before the first LDS-DMA)
+    if constexpr (SN) {
+        for (int c = tid; c < a.Cin; c += NTH) {
+            Sp[2 * c] = a.sn_a[c];
+            Sp[2 * c + 1] = a.sn_ib[c];
+        }
+    }
+
+    f32x16 acc[WT_PTS][RT];
+#pragma unroll
+    for (int k = 0; k < WT_PTS; k++)
+#pragma unroll
+        for (int i = 0; i < RT; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[k][i][r] = 0.0f;
+
+    const int xlim = ((a.Lin + 3) & ~3) - 4;
+    unsigned xo[XP], wo[WP];
+#pragma unroll
+    for (int j = 0; j < XP; j++) {
+        const int i = tid + NTH * j;
+        int row = i / xw4;
+        const int c4 = i - row * xw4;
+        row = row < WN_BK ? row : 0;                         // pieces past the window land in the buffer's padding
+        int pos = pwin0 + 4 * c4;
+        pos = pos < 0 ? 0 : (pos > xlim ? xlim : pos);
+        xo[j] = (unsigned)row * (unsigned)a.x_cs + (unsigned)pos;
+    }
+#pragma unroll
+    for (int k = 0; k < WP; k++) {                           // float4 index tid + NTH k of the [4][16][BN] image
+        int i = tid + NTH * k;
+        i = i < GEO::WF4 ? i : 0;                            // (pieces past the image re-read its start into the padding)
+        const int q = i / (WN_BK * BN / 4), rem = i - q * (WN_BK * BN / 4), r = rem / (BN / 4), c4 = rem - r * (BN / 4);
+        wo[k] = ((unsigned)q * (unsigned)CinP + (unsigned)r) * (unsigned)a.NP + (unsigned)c4 * 4u;
+    }
+    auto stage = [&](int cb, int buf) {
+        const float *xb = xu + (long)cb * WN_BK * a.x_cs;
+        float *xd = Xs + buf * XBUF + wave * 256;
+#pragma unroll
+        for (int j = 0; j < XP; j++)
+            __builtin_amdgcn_global_load_lds((wn_gptr_t)(xb + xo[j]), (wn_lptr_t)(xd + j * (NTH * 4)), 16, 0, 0);
+        const float *wb = a.ww + ((long)cb * WN_BK) * a.NP + n0;
+        float *wd = Ws + buf * WBUF + wave * 256;
+#pragma unroll
+        for (int k = 0; k < WP; k++)
+            __builtin_amdgcn_global_load_lds((wn_gptr_t)(wb + wo[k]), (wn_lptr_t)(wd + k * (NTH * 4)), 16, 0, 0);
+    };
+
+    __syncthreads();                                         // tables written (no DMA in flight yet)
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int cb = 0; cb < ncb; cb++) {
+        const int buf = cb & 1;
+        if (cb + 1 < ncb) stage(cb + 1, buf ^ 1);
+        {
+            const float *xs = Xs + buf * XBUF + xoff;
+            const float *ws = Ws + buf * WBUF + l31 + rw * (32 * RT);
+            const float *sp = Sp + 2 * (cb * WN_BK + h);
+            float dv[3][4], vv[2][WT_PTS], av[2][WT_PTS][RT];
+            float2 sv[3];
+            auto load_d = [&](int kk, int sl) {
+                const float *xk = xs + (2 * kk + h) * XW;
+#pragma unroll
+                for (int i = 0; i < 4; i++) dv[sl][i] = xk[i];
+                if constexpr (SN) sv[sl] = *reinterpret_cast<const float2 *>(sp + 4 * kk);
+            };
+            auto load_a = [&](int kk, int sl) {
+                const float *wk = ws + (2 * kk + h) * BN;
+#pragma unroll
+                for (int q = 0; q < WT_PTS; q++)
+#pragma unroll
+                    for (int i = 0; i < RT; i++) av[sl][q][i] = wk[q * (WN_BK * BN) + 32 * i];
+            };
+            auto transform = [&](int ds, int vs) {
+                float d[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) d[i] = (dmask >> i) & 1u ? dv[ds][i] : 0.0f;
+                if constexpr (SN) {
+                    const f32x2 ea = (f32x2)(sv[ds].x), ib = (f32x2)(sv[ds].y);
+#pragma unroll
+                    for (int i = 0; i < 4; i += 2) {
+                        const f32x2 r = snake_beta2(mk2(d[i], d[i + 1]), ea, ib);
+                        d[i] = r.x;
+                        d[i + 1] = r.y;
+                    }
+                }
+                vv[vs][0] = d[0] - d[2];
+                vv[vs][1] = d[1] + d[2];
+                vv[vs][2] = d[2] - d[1];
+                vv[vs][3] = d[3] - d[1];
+            };
+            load_d(0, 0);
+            load_a(0, 0);
+            load_d(1, 1);
+            transform(0, 0);
+#pragma unroll
+            for (int kk = 0; kk < WN_BK / 2; kk++) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk + 2 < WN_BK / 2) load_d(kk + 2, (kk + 2) % 3);
+                if (kk + 1 < WN_BK / 2) {
+                    load_a(kk + 1, (kk + 1) & 1);
+                    transform((kk + 1) % 3, (kk + 1) & 1);
+                }
+#pragma unroll
+                for (int q = 0; q < WT_PTS; q++)
+#pragma unroll
+                    for (int i = 0; i < RT; i++)
+                        acc[q][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk & 1][q][i], vv[kk & 1][q], acc[q][i], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < WT_PTS * RT; g++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // LDS reads
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);      // VALU in its shadow
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+
+    // ---- output transform and epilogue.  A lane holds three input steps of 16 RT rows; in memory a row (co, phase) is
+    // every S-th float of channel co, so storing from the accumulator layout would touch 3 S cache lines per 128 bytes
+    // written (measured: the stores, not the MFMAs, set the pace).  Instead every wave transposes its 32-row tile through
+    // its own slice of the (now idle) LDS and writes each channel's samples as one contiguous run, 256 bytes per
+    // instruction.  Rows are channel-major (n = co S + phase; the loader packs them so for this kernel).
+    float *yu = a.y + (long)unit * a.y_us;
+    float *y2u = a.y2 ? a.y2 + (long)unit * a.y_us : nullptr;
+    const int S = a.S;
+    constexpr int LTW = 97;                                   // padded row of the transposition tile (96 input steps)
+    float *Lt = Xs + wave * (32 * LTW);                       // this wave's slice (the loop ended with a barrier)
+    const int q0w = 3 * (T0 + tw * 32);                       // first input step of the wave's tiles
+    const int nq = a.M - q0w < 96 ? a.M - q0w : 96;           // steps of it that exist (<= 0: nothing to store)
+    const unsigned magic = 0xffffffffu / (unsigned)S + 1u;    // m / S for m < 2^16 as a multiply-high
+#pragma unroll
+    for (int i = 0; i < RT; i++) {
+        const int tr = (rw * RT + i) * 32;                    // first row of this tile inside the workgroup's rows
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const float m0 = acc[0][i][r], m1 = acc[1][i][r], m2 = acc[2][i][r], m3 = acc[3][i][r];
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const float b = a.bias ? Pm[tr + row] : 0.0f;
+            float *lp = Lt + row * LTW + 3 * l31;
+            lp[0] = ((m1 + m2) + m0) + b;
+            lp[1] = (m1 - m2) + b;
+            lp[2] = ((m1 + m2) + m3) + b;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // (one wave: its LDS operations complete in order)
+        const int nw = n0 + tr;                               // first global row of the tile
+        const int co_lo = nw / S, co_hi = (nw + 31) / S;
+        for (int co = co_lo; co <= co_hi; co++) {
+            const int rbase = co * S - nw;                    // tile row of phase 0 of this channel (may be < 0)
+            const int ph_lo = rbase < 0 ? -rbase : 0, ph_hi = rbase + S - 1 > 31 ? 31 - rbase : S - 1;
+            const long base = (long)co * a.y_cs + (long)q0w * S;
+            for (int m = lane; m < nq * S; m += 64) {
+                const int ql = (int)__umulhi((unsigned)m, magic), ph = m - ql * S;
+                if (ph < ph_lo || ph > ph_hi) continue;
+                const int row = rbase + ph;
+                float v = Lt[row * LTW + ql];
+                if (a.psn_a) {
+                    const float sv2 = snake_beta(v, Pm[2 * BN + tr + row], Pm[3 * BN + tr + row]);
+                    if (y2u) y2u[base + m] = sv2;
+                    else v = sv2;
+                }
+                yu[base + m] = v;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // reads done before the next tile overwrites the slice
+    }
+}
+
+// transposed conv of a decoder block in its Winograd form?
+static bool wino_tconv_selected(const ConvGemmArgs &a) {
+    return a.ntaps == 2 && a.S > 1 && a.shift_step == 1 && (a.shift0 == 0 || a.shift0 == -1) && a.units >= 1 && a.N == a.NP &&
+           (a.N % 128 == 0 || a.N % 96 == 0) && a.N % a.S == 0 && a.Cin % WN_BK == 0 && !a.res && !a.rscale && !a.xb && !a.yb &&
+           a.act == ACT_NONE && !a.in_elu && a.s2d <= 1 && a.y && (!a.y2 || a.psn_a) && a.M >= 1 && a.Lin >= 1 && !a.pm && a.S <= 32;
+}
+
 bool wino_selected(const ConvGemmArgs &a) {
     if (!a.ww || a.wb || a.w2) return false;
+    if (wino_tconv_selected(a)) return true;
     const int d = a.shift_step;
     return a.ntaps == 7 && a.S == 1 && (d == 1 || d == 3 || d == 9) && a.shift0 == -6 * d && a.units >= 1 && a.N == a.NP &&
            a.N % WN_BN == 0 && a.Cin % WN_BK == 0 && !a.res && !a.rscale && !a.y2 && !a.xb && !a.yb && a.act == ACT_NONE && !a.in_elu &&
@@ -286,6 +526,11 @@ bool wino_selected(const ConvGemmArgs &a) {
 
 static int wino_rt();
 const char *wino_kernel_name(const ConvGemmArgs &a) {      // as rocprofv3 prints it
+    if (wino_tconv_selected(a)) {
+        const bool big = a.N % 128 == 0;
+        if (a.sn_a) return big ? "wino_tconv_kernel<true,2,2>" : "wino_tconv_kernel<true,1,3>";
+        return big ? "wino_tconv_kernel<false,2,2>" : "wino_tconv_kernel<false,1,3>";
+    }
     static char names[2][3][2][40];
     const int di = a.shift_step == 1 ? 0 : a.shift_step == 3 ? 1 : 2, sn = a.sn_a ? 1 : 0, rt = wino_rt();
     char *n = names[sn][di][rt - 1];
@@ -327,9 +572,44 @@ static hipError_t wino_launch_one(const ConvGemmArgs &a, hipStream_t s) {
     return hipGetLastError();
 }
 
+template <bool SN, int RT, int RW>
+static hipError_t wino_tconv_launch_one(const ConvGemmArgs &a, hipStream_t s) {
+    using GEO = TconvGeom<RT, RW>;
+    const int n_tl = (a.M + 2) / 3;                          // tiles of three input steps
+    const int wg_per_unit = (n_tl + WN_NT - 1) / WN_NT;
+    const int n_tiles = a.N / GEO::BN;
+    const long grid = (long)wg_per_unit * a.units * n_tiles;
+    if (grid > 0x7fffffffL) return hipErrorInvalidValue;
+    // window: a workgroup's 128 tiles start at input position 3 T0 + sh, the window at most 3 before it, and the last
+    // read is 3*127 + 3 past the first tile's: XW = 3*128 + 8 covers it
+    size_t work = 2 * (size_t)GEO::XBUF + 2 * (size_t)GEO::WBUF;                 // staging buffers ...
+    const size_t lt = (size_t)(GEO::NTH / 64) * 32 * 97;                           // ... reused by the epilogue's transposition tiles
+    if (lt > work) work = lt;
+    const size_t lds = sizeof(float) * (4 * GEO::BN + (SN ? 2 * (size_t)a.Cin : 0) + work);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    static bool done[64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64 && !done[dev]) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(wino_tconv_kernel<SN, RT, RW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        done[dev] = true;
+    }
+    hipLaunchKernelGGL((wino_tconv_kernel<SN, RT, RW>), dim3((unsigned)grid), dim3(GEO::NTH), lds, s, a, wg_per_unit, n_tiles);
+    return hipGetLastError();
+}
+
 hipError_t launch_wino_conv7(const ConvGemmArgs &a, hipStream_t s) {
     if (!wino_selected(a)) return hipErrorInvalidValue;
     if (a.M <= 0) return hipSuccess;
+    if (wino_tconv_selected(a)) {
+        if ((a.x_cs & 3) || (a.x_us & 3) || ((uintptr_t)a.x & 15) || ((uintptr_t)a.ww & 15) || (a.NP & 3) || (a.sn_a && !a.sn_ib) || a.Cin > 4096)
+            return hipErrorInvalidValue;
+        const bool sn = a.sn_a != nullptr;
+        if (a.N % 128 == 0) return sn ? wino_tconv_launch_one<true, 2, 2>(a, s) : wino_tconv_launch_one<false, 2, 2>(a, s);
+        return sn ? wino_tconv_launch_one<true, 1, 3>(a, s) : wino_tconv_launch_one<false, 1, 3>(a, s);
+    }
     // host-side shape checks: what the kernel's 16-byte accesses assume
     if ((a.x_cs & 3) || (a.x_us & 3) || ((uintptr_t)a.x & 15) || ((uintptr_t)a.ww & 15) || (a.NP & 3) || a.Lin < 1 ||
         (a.sn_a && !a.sn_ib) || a.Cin > 4096)
