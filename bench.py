@@ -358,6 +358,13 @@ def main(argv=None):
                 r["executed_frac"] = round(achieved * 4 / 7 / peak, 4)
                 r["note"] = ("achieved = algorithmic (direct-form) FLOPs / time; the kernel is a Winograd F(2,7) convolution that "
                              "executes 4/7 of those multiplications on the matrix cores (executed_*)")
+            elif name.startswith("wino_tconv_kernel"):
+                # F(3,2) on the transposed conv (k = 2*stride: two taps per output phase): 4 multiplications per 3 outputs
+                # where the direct form has 6
+                r["executed_mfma_tflops"] = round(achieved * 4 / 6, 3)
+                r["executed_frac"] = round(achieved * 4 / 6 / peak, 4)
+                r["note"] = ("achieved = algorithmic (direct-form) FLOPs / time; the kernel is a Winograd F(3,2) transposed "
+                             "convolution that executes 4/6 of those multiplications on the matrix cores (executed_*)")
             return r
 
         dom = max(kernels, key=lambda n: kernels[n]["ms"])

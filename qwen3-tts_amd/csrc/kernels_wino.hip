@@ -12,13 +12,23 @@
 // (DESIGN.md section 4b has the measured waveform figures).
 //
 // Orientation as everywhere: weights are the A operand (rows = output channels), activations the B operand (column =
-// TILE on the lane).  A workgroup of 4 waves owns 64 output channels x 128 tiles (256 positions); wave w the tiles
-// [32w, 32w+32); every lane keeps 8 points x 2 row tiles = 16 accumulator tiles (256 registers: one wave per SIMD, one
-// workgroup per CU -- the K loop below is software-pipelined instead of relying on other waves).  K loop over blocks of
-// 16 input channels: the raw activation window Xs[16][XW] (SnakeBeta applied once per element at commit, as in
-// conv_gemm_kernel) and the eight transformed weight tiles Ws[8][16][64] are double-buffered in LDS, fetched one block
-// ahead through registers; ONE barrier per block (128 MFMAs per wave between barriers).  A lane reads its eight inputs
-// of channel k from Xs, forms the eight V_k (24 VALU instructions) and feeds each to the two MFMAs of its point.
+// TILE on the lane).  A workgroup owns 64 output channels x 128 tiles (256 positions).  Default (RT = 1): 8 waves, two
+// per SIMD; waves w and w + 4 own the tiles [32 (w & 3), +32) and one 32-row tile each, so a lane keeps 8 points x 16 =
+// 128 accumulator registers.  RT = 2 (HIPVOC_WINO_RT=2): 4 waves, one per SIMD, both row tiles per wave (256 accumulator
+// registers).  K loop over blocks of 16 input channels: the RAW activation window Xs[16][XW] and the eight transformed
+// weight tiles Ws[8][16][64] are double-buffered in LDS and fetched one block ahead by LDS-DMA (global_load_lds_dwordx4:
+// no staging registers, no commit pass; zero padding is applied when the window is read, from a per-lane mask); ONE
+// barrier per block (64 RT MFMAs per wave between barriers).  A lane reads its eight inputs of channel k from Xs, forms
+// the eight V_k (24 VALU instructions) and feeds each to the MFMAs of its point; the loop is software-pipelined by hand
+// (LDS reads two channels ahead, transform one ahead; sched_group_barrier interleaves them with the MFMAs).  The input's
+// SnakeBeta is normally applied by the PRODUCER of the tensor (dual outputs: the raw residual stream and the activated
+// operand, ConvGemmArgs::psn_*), so the window is a plain copy; the SN = true variant applies it on the fly for producers
+// that cannot (45 % slower: VALU-bound).
+//
+// wino_tconv_kernel further down: the decoder blocks' transposed convolutions (kernel = 2 x stride: every output phase is a
+// 2-tap filter over the input) by F(3,2): three consecutive input steps' outputs of a phase from 4 products instead of 6.
+// Its epilogue transposes each wave's tile through LDS so that every channel's run of q * S + phase outputs is written
+// contiguously.
 //
 // Dilation: tile T of a unit is the output pair (p, p + d) with p = 2d (T / d) + T % d, so consecutive tiles are
 // (almost) consecutive positions and both the LDS reads and the stores stay on neighbouring addresses.
