@@ -36,4 +36,5 @@ timeout -k 10 200 python3 tools/bf16_steps.py > $D/r02_steps_bf16_g64.txt 2>/dev
 timeout -k 10 200 python3 tools/bf16_steps.py x3 > $D/r02_steps_bf16x3_g64.txt 2>/dev/null || exit 1
 HIPVOC_WINO=0 timeout -k 10 200 python3 tools/profile_steps.py > $D/r02_steps_f32_g64_direct_kernels.txt 2>/dev/null || exit 1
 timeout -k 10 200 python3 tools/latency_breakdown.py > $D/r02_latency_single_utterance.txt 2>/dev/null || exit 1
+tools/prof_worker_r02.sh || exit 1
 echo r02 profiles done
