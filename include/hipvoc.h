@@ -138,16 +138,16 @@ int hipvoc_sync(void *h);
  * The entry point that allocates nothing.  It has NO counterpart in the reference; it is for callers that cannot call
  * hipMalloc: code under HIP graph capture, tight serving loops, harnesses that forbid allocation.  Same arguments,
  * kernels, launch plan and results (bit for bit) as hipvoc_decode_units_device, but the activation workspace is a
- * file-scope `static __device__` array of HIPVOC_NOALLOC_SCRATCH_BYTES (256 MiB) that each GPU the library runs on
+ * file-scope `static __device__` array of HIPVOC_NOALLOC_SCRATCH_BYTES (384 MiB) that each GPU the library runs on
  * holds until the process ends, instead of the handle's hipMalloc'ed buffers: no hipMalloc, hipFree, event or stream
  * creation happens in the call (the first call for a given n_units builds its launch plan, host memory only).
  * Limit: the pass must fit the array -- with the full-size decoder, 2 units of 64 frames (one 10 s utterance) in
- * fp32 / bf16x3, 1 unit in bf16; never more than 128 units.  Larger requests fail with HIPVOC_E_SCRATCH and the
+ * fp32 and bf16, 4 in bf16x3; never more than 128 units.  Larger requests fail with HIPVOC_E_SCRATCH and the
  * needed size in hipvoc_last_error; nothing is launched.  The array is cleared at the start of every call.  All
  * handles on one GPU share that GPU's array: calls that overlap on one GPU (two handles, two threads) race -- keep
  * them serialised.  Work is enqueued on the handle's stream like hipvoc_decode_units_device.
  */
-#define HIPVOC_NOALLOC_SCRATCH_BYTES (256u << 20)
+#define HIPVOC_NOALLOC_SCRATCH_BYTES (384u << 20)
 int hipvoc_decode_units_device_noalloc(void *h, const int64_t *d_codes, int n_units, float *d_out, size_t unit_stride);
 
 /* The hipStream_t the handle launches on (for hipEvent timing by the caller). */

@@ -127,6 +127,7 @@ struct Ctx {
     bool packed = true;        // bf16 mode: GEMM-to-GEMM tensors of the decoder stack exchanged as packed bf16 (HIPVOC_PACKED=0: fp32)
     bool wino_tconv = true;    // fp32 mode: the decoder blocks' transposed convs by F(3,2) (HIPVOC_WINO_TCONV=0: direct)
     bool wino_unfuse = true;   // blocks whose residual units could be fused run un-fused when their conv7 has a Winograd form (HIPVOC_WINO_UNFUSE=0)
+    bool wino_unit = true;     // fp32 mode: residual units of a 96-channel block as ONE Winograd kernel each (wino_ps_kernel<D,3,true>; HIPVOC_WINO_UNIT=0: the fused direct kernel)
     bool wino = true;          // fp32 mode: k = 7 convs of the un-fused residual units by Winograd F(2,7) (HIPVOC_WINO=0: direct)
     bool trim_right = false;   // trans-conv trim policy (metadata transconv_trim_right_only=1): keep L*r samples instead of (L-1)*r
     bool is_encoder = false;   // handle made by hipvoc_enc_load (encoder.inc.cpp): the vocoder entry points refuse it
@@ -159,6 +160,7 @@ struct Ctx {
     float *fin_w_raw = nullptr;   // [C][K] for the dedicated final-stage kernel
     float *cos_t = nullptr, *sin_t = nullptr;
     int *d_err = nullptr;
+    const float *d_zeros = nullptr;   // 256 bytes of zeros, never written: DMA source of the causal left padding (kernels_wino.hip)
 
     // workspace (sized for `group` units of `unit_frames`)
     std::map<int, std::pair<float *, size_t>> bufs;
@@ -418,7 +420,8 @@ struct Loader {
         finish(g, p, CinP);
         // Winograd F(2,7) form of the k = 7 convs (fp32 mode): U_k = sum_j G[k][j] w_j for the points 0, +-1, +-2, +-1/2, inf,
         // in double, rounded once.  Used when the layer qualifies (kernels_wino.hip: wino_selected).
-        if (c->wino && !c->bf16 && K == 7 && g.N == g.NP && g.N % 64 == 0 && Cin % 16 == 0 && (dil == 1 || dil == 3 || dil == 9)) {
+        if (c->wino && !c->bf16 && K == 7 && g.N == g.NP && (g.N % 64 == 0 || (g.N == 96 && Cin == 96 && c->wino_unit)) && Cin % 16 == 0 &&
+            (dil == 1 || dil == 3 || dil == 9)) {
             static const double Gm[8][7] = {
                 {1, 0, 0, 0, 0, 0, 0},
                 {-2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9},
@@ -670,6 +673,7 @@ static bool load_model(Ctx *c, const char *path, std::string &err) {
     }
     std::vector<float> z(4, 0.0f);
     c->d_err = (int *)L.upload(z);
+    c->d_zeros = L.upload(std::vector<float>(64, 0.0f));
     if (!L.ok) { err = L.err; return false; }
     if (c->out_len(c->unit_frames) <= 0) { err = "unit_frames too small for this topology"; return false; }
     return true;
@@ -677,7 +681,7 @@ static bool load_model(Ctx *c, const char *path, std::string &err) {
 
 // ---------------------------------------------------------------------------------------------
 // workspace + plan
-enum BufId { B_RVQ = 1, B_SUMS, B_PRE, B_H, B_XN, B_QKV, B_AO, B_GU, B_BIG0, B_BIG1, B_BIG2, B_SNK, B_PK0, B_PK1 };
+enum BufId { B_RVQ = 1, B_SUMS, B_PRE, B_H, B_XN, B_QKV, B_AO, B_GU, B_BIG0, B_BIG1, B_BIG2, B_SNK, B_PK0, B_PK1, B_SNK2 };
 
 struct PlanBuilder {
     Ctx *c;
@@ -738,6 +742,7 @@ struct PlanBuilder {
         a.in_elu = in_elu;
         a.s2d = s2d;
         a.ww = g.ww;
+        a.zeros = c->d_zeros;
         a.x = x; a.y = y; a.w = g.w; a.wb = g.wb; a.wbm = g.wbm; a.bias = g.bias; a.res = res; a.rscale = rscale; a.y2 = post ? y2 : nullptr;
         a.xb = xb; a.yb = yb;
         a.psn_a = post ? post->ea : nullptr; a.psn_ib = post ? post->ib : nullptr;
@@ -786,6 +791,24 @@ struct PlanBuilder {
             const double el = (double)c1.N * G * L;      // operand in (packed or fp32), fp32 residual in, fp32 / packed out
             p->steps.back().bytes = el * (xb ? 2 : 4) + (xb ? el * 4 : 0) + (y ? el * 4 : 0) + (yb ? el * 2 : 0);
         }
+    }
+    // The same residual unit as ONE Winograd kernel (kernels_wino.hip: wino_ps_kernel<D, 3, true>; N = Cin = 96): conv7 by F(2,7),
+    // SnakeBeta, the 1x1 conv and the residual add in registers.  xs = snake_s1(x), written by the producer (the kernel fetches
+    // its operand by DMA); x = the raw residual stream; y = the raw output; ys (may be null) = post(y) beside it for the next
+    // unit -- NOT the buffer xs: neighbouring workgroups still read its halo.  post without ys: y itself is post(out).
+    void res_unit_wino(const char *name, const Gemm &c1, const Gemm &c2, const Snake &s2, const float *xs, const float *x, int L, int Lp,
+                       float *y, const Snake *post, float *ys) {
+        ConvGemmArgs a{};
+        a.psn_a = post ? post->ea : nullptr; a.psn_ib = post ? post->ib : nullptr;
+        a.x = xs; a.y = y; a.y2 = post ? ys : nullptr; a.ww = c1.ww; a.w = c1.w; a.zeros = c->d_zeros; a.bias = c1.bias; a.res = x;
+        a.w2 = c2.w; a.bias2 = c2.bias; a.sn2_a = s2.ea; a.sn2_ib = s2.ib;
+        a.Cin = c1.Cin; a.N = c1.N; a.NP = c1.NP; a.TN = c1.TN;
+        a.ntaps = c1.ntaps; a.shift0 = c1.shift0; a.shift_step = c1.step; a.S = 1; a.act = ACT_NONE;
+        a.units = G; a.M = L; a.Lin = L; a.x_us = Lp; a.y_us = Lp; a.x_cs = (long)G * Lp; a.y_cs = (long)G * Lp;
+        double macs = (double)G * L * c1.N * ((double)c1.Cin * c1.ntaps + c2.Cin);
+        add(name, conv_gemm_kernel_name(a), macs, [a](hipStream_t s) { return launch_conv_gemm(a, s); });
+        const double el = (double)c1.N * G * L;              // activated operand + raw residual in, raw (+ activated) out
+        p->steps.back().bytes = el * 4 * (3 + (a.y2 ? 1 : 0));
     }
 };
 
@@ -865,14 +888,23 @@ static std::unique_ptr<Plan> build_plan(Ctx *c, int G, int T, bool debug, char *
     // does not fit one workgroup) and with SnakeBeta in the producers' epilogues (dual outputs: the raw residual stream
     // and the activated tensor side by side), so that the conv reads its operand straight into LDS by DMA.
     auto blk_wino = [c](const Ctx::Block &blk) {
-        return c->wino && !c->bf16 && blk.res[0].c1.ww && blk.res[1].c1.ww && blk.res[2].c1.ww;
+        return c->wino && !c->bf16 && blk.res[0].c1.ww && blk.res[1].c1.ww && blk.res[2].c1.ww && blk.res[0].c1.N % 64 == 0;
+    };
+    // ... and a block of 96 channels keeps whole residual units in one kernel (PlanBuilder::res_unit_wino)
+    auto blk_wino_unit = [c](const Ctx::Block &blk) {
+        if (!(c->wino && c->wino_unit && !c->bf16)) return false;
+        for (int u = 0; u < 3; u++) {
+            const Ctx::Res &ru = blk.res[u];
+            if (!ru.c1.ww || ru.c1.N != 96 || ru.c1.Cin != 96 || ru.c1.NP != 96 || !PlanBuilder::can_fuse(ru.c1, ru.c2) || ru.c2.NP != 96) return false;
+        }
+        return true;
     };
     auto blk_fused = [c, blk_wino](const Ctx::Block &blk) {
         if (c->wino_unfuse && blk_wino(blk)) return false;
         return c->fuse_res && PlanBuilder::can_fuse(blk.res[0].c1, blk.res[0].c2) &&
                PlanBuilder::can_fuse(blk.res[1].c1, blk.res[1].c2) && PlanBuilder::can_fuse(blk.res[2].c1, blk.res[2].c2);
     };
-    size_t big = 0, big2 = 0, snk_floats = 0;      // big2: the third buffer only ever holds a ConvNeXt block's hidden tensor
+    size_t big = 0, big2 = 0, snk_floats = 0, snk2_floats = 0;      // big2: the third buffer only ever holds a ConvNeXt block's hidden tensor
     {
         long L = T;
         int C = c->latent;
@@ -889,12 +921,18 @@ static std::unique_ptr<Plan> build_plan(Ctx *c, int G, int T, bool debug, char *
             C = c->blocks[i].tc.N / c->rates[i];
             big = std::max(big, (size_t)C * rowlen((int)L));
             if ((c->dual_out >= 2 || blk_wino(c->blocks[i])) && !blk_fused(c->blocks[i])) snk_floats = std::max(snk_floats, (size_t)C * rowlen((int)L) * G);
+            if (blk_wino_unit(c->blocks[i])) {              // activated tensors ping-pong between two buffers there
+                snk_floats = std::max(snk_floats, (size_t)C * rowlen((int)L) * G);
+                snk2_floats = std::max(snk2_floats, (size_t)C * rowlen((int)L) * G);
+            }
         }
         big *= G;
         big2 *= G;
     }
     float *snk_buf = snk_floats ? b.buf(B_SNK, snk_floats) : nullptr;
     if (snk_floats && !snk_buf) return nullptr;
+    float *snk2_buf = snk2_floats ? b.buf(B_SNK2, snk2_floats) : nullptr;
+    if (snk2_floats && !snk2_buf) return nullptr;
     float *cur = b.buf(B_BIG0, big), *t1 = b.buf(B_BIG1, big), *t2 = b.buf(B_BIG2, big2);
     if (b.fail || !cur || !t1 || !t2) return nullptr;
     b.gemm("proj", c->out_proj, xn, T, Tp, cur, Tp, nullptr, nullptr, nullptr, ACT_NONE);
@@ -1005,10 +1043,11 @@ static std::unique_ptr<Plan> build_plan(Ctx *c, int G, int T, bool debug, char *
             // staging loop once per row tile: the trans-conv / the previous unit's conv1 write x (raw, the residual)
             // and snake_s1(x) side by side; conv7 writes snake_s2(H) only.  Same fp32 operations on the same values,
             // so results are bit-identical to the consumer-side form.
-            const bool fused_blk = blk_fused(blk);
-            const bool dual = (c->dual_out >= 2 || blk_wino(blk)) && !fused_blk;
+            const bool wino_unit = blk_wino_unit(blk);
+            const bool fused_blk = blk_fused(blk) && !wino_unit;
+            const bool dual = ((c->dual_out >= 2 || blk_wino(blk)) && !fused_blk) || wino_unit;
             const int Cn = blk.tc.N / r;
-            float *snk = dual ? snk_buf : nullptr;
+            float *snk = dual ? snk_buf : nullptr, *snk_other = snk2_buf;
             b.gemm(tc_names[ni], blk.tc, cur, L, Lp, t1, Lp2, post_snake ? nullptr : &blk.s, nullptr, nullptr, ACT_NONE,
                    dual ? &blk.res[0].s1 : nullptr, snk);
             std::swap(cur, t1);
@@ -1017,7 +1056,12 @@ static std::unique_ptr<Plan> build_plan(Ctx *c, int G, int T, bool debug, char *
             for (int u = 0; u < 3; u++) {
                 const Ctx::Res &ru = blk.res[u];
                 const Snake *post = (post_snake && u == 2 && bi + 1 < c->blocks.size()) ? &c->blocks[bi + 1].s : nullptr;
-                if (fused_blk) {
+                if (wino_unit) {
+                    const Snake *nxt = u < 2 ? &blk.res[u + 1].s1 : post;
+                    b.res_unit_wino(ru_names[ni], ru.c1, ru.c2, ru.s2, snk, cur, L, Lp, t1, nxt, u < 2 ? snk_other : nullptr);
+                    std::swap(cur, t1);
+                    std::swap(snk, snk_other);
+                } else if (fused_blk) {
                     b.res_unit_fused(ru_names[ni], ru.c1, ru.c2, ru.s1, ru.s2, cur, L, Lp, t1, post);
                     std::swap(cur, t1);
                 } else if (dual) {
@@ -1390,6 +1434,7 @@ static void *load_impl(const char *weights_path, int device_id, int dtype, int u
     if (const char *ps = getenv("HIPVOC_WINO")) c->wino = atoi(ps) != 0;
     if (const char *ps = getenv("HIPVOC_WINO_UNFUSE")) c->wino_unfuse = atoi(ps) != 0;
     if (const char *ps = getenv("HIPVOC_WINO_TCONV")) c->wino_tconv = atoi(ps) != 0;
+    if (const char *ps = getenv("HIPVOC_WINO_UNIT")) c->wino_unit = atoi(ps) != 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
     {   // this device's copy of the static scratch array of hipvoc_decode_units_device_noalloc (scratch.hip): resolved
         // here, once per device, with the device current

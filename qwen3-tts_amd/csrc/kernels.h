@@ -56,6 +56,7 @@ struct ConvGemmArgs {
     // set and the layer qualifies (wino_selected) the conv runs on wino_conv7_kernel -- at EVERY launch size, so that
     // batch == single holds bit for bit -- else on the direct kernels from `w`
     const float *ww;
+    const float *zeros;              // >= 16 bytes of zeros in device memory (wino_conv7_kernel: source of the causal left padding)
     int Cin, N, NP, TN;
     int ntaps, shift0, shift_step;   // shift(tap) = shift0 + tap*shift_step
     int S;                           // out channel = n / S, out position = m*S + n % S

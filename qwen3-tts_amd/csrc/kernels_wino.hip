@@ -17,7 +17,7 @@
 // 128 accumulator registers.  RT = 2 (HIPVOC_WINO_RT=2): 4 waves, one per SIMD, both row tiles per wave (256 accumulator
 // registers).  K loop over blocks of 16 input channels: the RAW activation window Xs[16][XW] and the eight transformed
 // weight tiles Ws[8][16][64] are double-buffered in LDS and fetched one block ahead by LDS-DMA (global_load_lds_dwordx4:
-// no staging registers, no commit pass; zero padding is applied when the window is read, from a per-lane mask); ONE
+// no staging registers, no commit pass; the causal zero padding is fetched from a page of zeros, see below); ONE
 // barrier per block (64 RT MFMAs per wave between barriers).  A lane reads its eight inputs of channel k from Xs, forms
 // the eight V_k (24 VALU instructions) and feeds each to the MFMAs of its point; the loop is software-pipelined by hand
 // (LDS reads two channels ahead, transform one ahead; sched_group_barrier interleaves them with the MFMAs).  The input's
@@ -42,34 +42,76 @@ namespace hipvoc {
 
 static constexpr int WN_BK = 16;      // input channels per K stage
 static constexpr int WN_NT = 128;     // tiles per workgroup (4 waves x 32)
-static constexpr int WN_BN = 64;      // output channels per workgroup (2 row tiles)
 static constexpr int WN_PTS = 8;
+#ifndef WN_VG
+#define WN_VG 8
+#endif
+#ifndef WN_MASK
+#define WN_MASK 0
+#endif
+#ifndef WN_ZP
+#define WN_ZP 1
+#endif
+#ifndef WN_DD
+#define WN_DD 3
+#endif
+#ifndef WN_ASMDMA
+#define WN_ASMDMA 1
+#endif
+#ifndef WN_MODE_DEFAULT
+#define WN_MODE_DEFAULT 4
+#endif
+#ifndef WN_KATTR
+#define WN_KATTR
+#endif
+#ifndef PS_ABL
+#define PS_ABL 0   // timing-only ablation bits (results are wrong with any set)
+#endif
+#ifndef WN_DG
+#define WN_DG 2
+#endif
 static constexpr bool wino_order_pin = false;  // (measured: LDS reads of a step first in program order, then MFMAs: 7.31 ms on b1 against 7.05 interleaved)
 
 // RT = row tiles (32 output channels each) per wave: 2 -> 4 waves per workgroup, one wave per SIMD (256 accumulator
 // registers); 1 -> 8 waves, two per SIMD: waves w and w + 4 own the same tiles and one row tile each.
-template <int D, int RT>
+template <int D, int RT, int RH>
 struct WinoGeom {
-    static constexpr int NTH = RT == 2 ? 256 : 512;
+    static constexpr int NTH = 4 * RH * 64;                               // 4 tile groups x RH row groups of waves
+    static constexpr int BN = 32 * RT * RH;                               // output channels per workgroup
     static constexpr int XW = (257 + 10 * D + 3) & ~3;                    // raw window: see the bound in launch_wino_conv7
     static constexpr int XP = (WN_BK * (XW / 4) + NTH - 1) / NTH;         // LDS-DMA pieces (16 B per lane) of the window per thread
-    static constexpr int XBUF = XP * NTH * 4;                             // floats per window buffer (whole pieces: the tail is padding)
-    static constexpr int WP = WN_PTS * WN_BK * WN_BN / 4 / NTH;           // pieces of the weight tiles per thread
+    static constexpr int XBUF = WN_BK * XW;                               // floats per window buffer (the last piece of a thread may not exist)
+    static constexpr int WP = WN_PTS * WN_BK * BN / 4 / NTH;              // pieces of the weight tiles per thread
+    static constexpr int WBUF = WN_PTS * WN_BK * BN;                      // floats per weight buffer
 };
-static constexpr int WN_WBUF = WN_PTS * WN_BK * WN_BN;                    // floats per weight buffer
 
 typedef __attribute__((address_space(1))) const void *wn_gptr_t;
 typedef __attribute__((address_space(3))) void *wn_lptr_t;
 
+// 16 bytes per lane from global memory straight into LDS (wave-uniform LDS base in M0 + 16 * lane).  Issued as inline asm,
+// not through __builtin_amdgcn_global_load_lds: the compiler books that builtin as a FLAT access to both address spaces
+// ("pending flat"), and while one is in flight -- here: always -- every wait for an LDS read becomes lgkmcnt(0) instead of
+// the count that lets younger reads stay in flight.  The kernels below wait for their DMA themselves (vmcnt(0) before the
+// block barrier) and use M0 for nothing else.
+__device__ __forceinline__ void wn_dma16(const float *g, float *lds) {
+#if WN_ASMDMA
+    const unsigned l = (unsigned)(size_t)(wn_lptr_t)lds;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(l), "v"(g) : "memory");
+#else
+    __builtin_amdgcn_global_load_lds((wn_gptr_t)g, (wn_lptr_t)lds, 16, 0, 0);
+#endif
+}
+
 // SN: the conv has a SnakeBeta prologue (a.sn_a / a.sn_ib), applied to the inputs as they are read from LDS
-template <int D, bool SN, int RT>
-__global__ __launch_bounds__((WinoGeom<D, RT>::NTH), 1) void wino_conv7_kernel(ConvGemmArgs a, int wg_per_unit, int n_tiles) {
-    using GEO = WinoGeom<D, RT>;
+template <int D, bool SN, int RT, int RH>
+__global__ __launch_bounds__((WinoGeom<D, RT, RH>::NTH), (RT * RH == 1 ? 2 : 1)) WN_KATTR void wino_conv7_kernel(ConvGemmArgs a, int wg_per_unit, int n_tiles) {
+    using GEO = WinoGeom<D, RT, RH>;
+    constexpr int BN = GEO::BN, WN_WBUF = GEO::WBUF;
     constexpr int NTH = GEO::NTH, XW = GEO::XW, XP = GEO::XP, XBUF = GEO::XBUF, WP = GEO::WP, xw4 = XW / 4;
     // ONE LDS array (a second object beside LDS-DMA staging makes hipcc wait vmcnt(0) before every ds_read)
     extern __shared__ __attribute__((aligned(16))) float smem_all[];
     float *Pm = smem_all;                                   // [4][64] per-row parameters (device_common.h)
-    float *Sp = smem_all + 4 * WN_BN;                       // [Cin][2] SnakeBeta parameters of the input channels (SN)
+    float *Sp = smem_all + 4 * BN;                       // [Cin][2] SnakeBeta parameters of the input channels (SN)
     float *Xs = Sp + (SN ? 2 * a.Cin : 0);                  // [2][XBUF]: raw activation window, rows of XW floats
     float *Ws = Xs + 2 * XBUF;                              // [2][8][16][64]
 
@@ -80,7 +122,7 @@ __global__ __launch_bounds__((WinoGeom<D, RT>::NTH), 1) void wino_conv7_kernel(C
     const int pt = id / n_tiles;
     const int unit = pt / wg_per_unit;
     const int T0 = (pt - unit * wg_per_unit) * WN_NT;
-    const int n0 = nt * WN_BN;
+    const int n0 = nt * BN;
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l31 = lane & 31, h = lane >> 5;
@@ -92,23 +134,25 @@ __global__ __launch_bounds__((WinoGeom<D, RT>::NTH), 1) void wino_conv7_kernel(C
     const int p0 = 2 * D * (T0 / D) + T0 % D;
     const int pwin0 = (p0 - 6 * D) & ~3;                    // (floor to a multiple of 4, also when negative)
     // this lane's tile: outputs p and p + D from the inputs p - 6D + i D, i = 0..7
-    const int tw = wave & 3, rh = RT == 2 ? 0 : wave >> 2;      // tile group of this wave, its row tile (RT == 1)
+    const int tw = wave & 3, rh = wave >> 2;                    // tile group of this wave, its row group (RT row tiles)
     const int T = T0 + tw * 32 + l31;
     const int tq = T / D, tph = T - tq * D;
     const int p = 2 * D * tq + tph;
     const int xoff = p - 6 * D - pwin0;                     // >= 0; xoff + 7 D < XW
-    // which of the eight inputs exist (causal zero padding on the left, the end of the unit on the right): the window is
-    // fetched from clamped addresses, what must read as zero is zeroed here
     unsigned dmask = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         const int pi = p + (i - 6) * D;
         dmask |= (pi >= 0 && pi < a.Lin) ? (1u << i) : 0u;
     }
-
+    // Inputs that do not exist.  LEFT of the unit (causal zero padding): position 0 is a multiple of 4 in the window's
+    // 16-byte pieces, so such inputs are whole pieces, and those are fetched from a page of zeros instead of the tensor (zsrc
+    // below).  RIGHT of the unit (positions >= Lin = M): the only input of a tile that can lie there while the tile's first
+    // output p is stored is x[p + D], which enters V7 alone, and M7 enters y1 = y[p + D] alone -- an output that is not stored.
+    // So whatever the (clamped, finite) fetch delivers there never reaches memory, and the loop needs no per-lane masks.
     // ---- parameter tables: ordinary loads, all BEFORE the first LDS-DMA (hipcc drains every DMA in flight at the next
     // use of an ordinary load's result)
-    fill_param_table<WN_BN, false>(a, Pm, n0, tid, NTH);
+    fill_param_table<BN, false>(a, Pm, n0, tid, NTH);
     if constexpr (SN) {
         for (int c = tid; c < a.Cin; c += NTH) {
             Sp[2 * c] = a.sn_a[c];
@@ -128,14 +172,15 @@ __global__ __launch_bounds__((WinoGeom<D, RT>::NTH), 1) void wino_conv7_kernel(C
     // wave-instruction is lane-linear (64 x 16 B), so piece j of the window is float4 index 256 j + tid of the [16][XW]
     // image and its per-lane SOURCE address does the row / clamp arithmetic; weight tile k is a plain copy.
     const int xlim = ((a.Lin + 3) & ~3) - 4;
-    unsigned xo[XP];
+    unsigned xo[XP], zsrc = 0;
 #pragma unroll
     for (int j = 0; j < XP; j++) {
         const int i = tid + NTH * j;
         int row = i / xw4;
         const int c4 = i - row * xw4;
-        row = row < WN_BK ? row : 0;                         // pieces past the window land in the buffer's padding
+        row = row < WN_BK ? row : 0;                         // (pieces past the window are not issued)
         int pos = pwin0 + 4 * c4;
+        zsrc |= pos < 0 ? (1u << j) : 0u;
         pos = pos < 0 ? 0 : (pos > xlim ? xlim : pos);
         xo[j] = (unsigned)row * (unsigned)a.x_cs + (unsigned)pos;
     }
@@ -143,20 +188,22 @@ __global__ __launch_bounds__((WinoGeom<D, RT>::NTH), 1) void wino_conv7_kernel(C
     unsigned wo[WP];
 #pragma unroll
     for (int k = 0; k < WP; k++) {
-        const int i = tid + NTH * k, q = i >> 8, r = (i >> 4) & 15, c4 = i & 15;
+        const int i = tid + NTH * k, q = i / (4 * BN), r = (i / (BN / 4)) & 15, c4 = i % (BN / 4);
         wo[k] = ((unsigned)q * (unsigned)CinP + (unsigned)r) * (unsigned)a.NP + (unsigned)c4 * 4u;
     }
     auto stage = [&](int cb, int buf) {
         const float *xb = xu + (long)cb * WN_BK * a.x_cs;
         float *xd = Xs + buf * XBUF + wave * 256;
 #pragma unroll
-        for (int j = 0; j < XP; j++)
-            __builtin_amdgcn_global_load_lds((wn_gptr_t)(xb + xo[j]), (wn_lptr_t)(xd + j * (NTH * 4)), 16, 0, 0);
+        for (int j = 0; j < XP; j++) {
+            const float *src = (WN_ZP && ((zsrc >> j) & 1u)) ? a.zeros : xb + xo[j];
+            if (NTH * (j + 1) <= WN_BK * xw4 || tid + NTH * j < WN_BK * xw4) wn_dma16(src, xd + j * (NTH * 4));
+        }
         const float *wb = a.ww + ((long)cb * WN_BK) * a.NP + n0;
         float *wd = Ws + buf * WN_WBUF + wave * 256;
 #pragma unroll
         for (int k = 0; k < WP; k++)
-            __builtin_amdgcn_global_load_lds((wn_gptr_t)(wb + wo[k]), (wn_lptr_t)(wd + k * (NTH * 4)), 16, 0, 0);
+            wn_dma16(wb + wo[k], wd + k * (NTH * 4));
     };
 
     __syncthreads();                                         // tables written (no DMA in flight yet)
@@ -167,10 +214,10 @@ __global__ __launch_bounds__((WinoGeom<D, RT>::NTH), 1) void wino_conv7_kernel(C
         if (cb + 1 < ncb) stage(cb + 1, buf ^ 1);            // lands during this block's MFMAs; the other buffer has no readers
         {
             const float *xs = Xs + buf * XBUF + xoff;
-            const float *ws = Ws + buf * WN_WBUF + l31 + rh * 32;
+            const float *ws = Ws + buf * WN_WBUF + l31 + rh * (32 * RT);
             const float *sp = Sp + 2 * (cb * WN_BK + h);
-            float dv[3][8], vv[2][WN_PTS], av[2][WN_PTS][RT];
-            float2 sv[3];
+            float dv[WN_DD][8], vv[2][WN_PTS], av[2][WN_PTS][RT];
+            float2 sv[WN_DD];
             auto load_d = [&](int kk, int sl) {
                 const float *xk = xs + (2 * kk + h) * XW;
 #pragma unroll
@@ -178,17 +225,17 @@ __global__ __launch_bounds__((WinoGeom<D, RT>::NTH), 1) void wino_conv7_kernel(C
                 if constexpr (SN) sv[sl] = *reinterpret_cast<const float2 *>(sp + 4 * kk);
             };
             auto load_a = [&](int kk, int sl) {
-                const float *wk = ws + (2 * kk + h) * WN_BN;
+                const float *wk = ws + (2 * kk + h) * BN;
 #pragma unroll
                 for (int q = 0; q < WN_PTS; q++)
 #pragma unroll
-                    for (int i = 0; i < RT; i++) av[sl][q][i] = wk[q * (WN_BK * WN_BN) + 32 * i];
+                    for (int i = 0; i < RT; i++) av[sl][q][i] = wk[q * (WN_BK * BN) + 32 * i];
             };
-            // zero padding, SnakeBeta (snake(0) == 0 keeps the padding), then V = B^T d for the points 0, 1, -1, 2, -2, 1/2, -1/2, inf
+            // SnakeBeta (snake(0) == 0 keeps the zero padding), then V = B^T d for the points 0, 1, -1, 2, -2, 1/2, -1/2, inf
             auto transform = [&](int ds, int vs) {
                 float d[8];
 #pragma unroll
-                for (int i = 0; i < 8; i++) d[i] = (dmask >> i) & 1u ? dv[ds][i] : 0.0f;
+                for (int i = 0; i < 8; i++) d[i] = WN_MASK ? (((dmask >> i) & 1u) ? dv[ds][i] : 0.0f) : dv[ds][i];
                 if constexpr (SN) {
                     const f32x2 ea = (f32x2)(sv[ds].x), ib = (f32x2)(sv[ds].y);
 #pragma unroll
@@ -199,16 +246,19 @@ __global__ __launch_bounds__((WinoGeom<D, RT>::NTH), 1) void wino_conv7_kernel(C
                     }
                 }
                 const float d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3], d4 = d[4], d5 = d[5], d6 = d[6], d7 = d[7];
-                const float e12 = fmaf(-4.25f, d4, d2) + d6, o12 = fmaf(-4.25f, d3, d1) + d5;
-                const float e34 = fmaf(0.25f, d2, fmaf(-1.25f, d4, d6)), o34 = fmaf(0.5f, d1, fmaf(-2.5f, d3, 2.0f * d5));
-                const float e56 = fmaf(4.0f, d2, fmaf(-5.0f, d4, d6)), o56 = fmaf(2.0f, d1, fmaf(-2.5f, d3, 0.5f * d5));
+                // 24 VALU instructions (on gfx950 every fp32 VALU instruction takes its ~4 cycles from the fp32 matrix pipe --
+                // tools/ubench/mfma_valu2.hip -- so this count, not latency, is what the transform costs).  The odd parts of
+                // the +-2 and +-1/2 points are kept at the scale whose first coefficient is 1 and rescaled by the final fma.
+                const float e12 = fmaf(-4.25f, d4, d2 + d6), o12 = fmaf(-4.25f, d3, d1 + d5);
+                const float e34 = fmaf(0.25f, d2, fmaf(-1.25f, d4, d6)), o34 = fmaf(4.0f, d5, fmaf(-5.0f, d3, d1));      // 2 x odd part
+                const float e56 = fmaf(4.0f, d2, fmaf(-5.0f, d4, d6)), o56 = fmaf(0.25f, d5, fmaf(-1.25f, d3, d1));     // odd part / 2
                 vv[vs][0] = fmaf(5.25f, d4 - d2, d0 - d6);
                 vv[vs][1] = e12 + o12;
                 vv[vs][2] = e12 - o12;
-                vv[vs][3] = e34 + o34;
-                vv[vs][4] = e34 - o34;
-                vv[vs][5] = e56 + o56;
-                vv[vs][6] = e56 - o56;
+                vv[vs][3] = fmaf(0.5f, o34, e34);
+                vv[vs][4] = fmaf(-0.5f, o34, e34);
+                vv[vs][5] = fmaf(2.0f, o56, e56);
+                vv[vs][6] = fmaf(-2.0f, o56, e56);
                 vv[vs][7] = fmaf(5.25f, d3 - d5, d7 - d1);
             };
             // One wave per SIMD: only this wave's own instruction stream hides latency.  Three-deep pipeline over the eight
@@ -217,15 +267,18 @@ __global__ __launch_bounds__((WinoGeom<D, RT>::NTH), 1) void wino_conv7_kernel(C
             // that sched_group_barrier interleaves around the MFMAs.
             load_d(0, 0);
             load_a(0, 0);
-            load_d(1, 1);
+#pragma unroll
+            for (int j = 1; j < WN_DD - 1; j++) load_d(j, j);
             transform(0, 0);
 #pragma unroll
             for (int kk = 0; kk < WN_BK / 2; kk++) {
                 __builtin_amdgcn_sched_barrier(0);
+                // weights of the next step first, inputs of step kk + WN_DD - 1 after them: LDS returns in order, so the
+                // next step's first MFMA waits for the weights only (lgkmcnt(n > 0)), and the inputs have a whole step more
                 if (kk + 1 < WN_BK / 2) load_a(kk + 1, (kk + 1) & 1);
-                if (kk + 2 < WN_BK / 2) load_d(kk + 2, (kk + 2) % 3);
+                if (kk + WN_DD - 1 < WN_BK / 2) load_d(kk + WN_DD - 1, (kk + WN_DD - 1) % WN_DD);
                 if (wino_order_pin) __builtin_amdgcn_sched_barrier(0);
-                if (kk + 1 < WN_BK / 2) transform((kk + 1) % 3, (kk + 1) & 1);
+                if (kk + 1 < WN_BK / 2) transform((kk + 1) % WN_DD, (kk + 1) & 1);
 #pragma unroll
                 for (int q = 0; q < WN_PTS; q++)
 #pragma unroll
@@ -248,8 +301,8 @@ __global__ __launch_bounds__((WinoGeom<D, RT>::NTH), 1) void wino_conv7_kernel(C
 #pragma unroll
                     for (int g = 0; g < 8; g++) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, WN_DG, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, WN_VG, 0);
                     }
                 }
             }
@@ -276,18 +329,313 @@ __global__ __launch_bounds__((WinoGeom<D, RT>::NTH), 1) void wino_conv7_kernel(C
                 y0[e] = ((m1 + m2) + (m3 + m4)) + ((m5 + m6) + m0);
                 y1[e] = fmaf(2.0f, m3 - m4, m1 - m2) + fmaf(0.5f, m5 - m6, m7);
             }
-            const int row = (i + rh) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;   // rows row, row + 1
+            const int row = (rh * RT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;   // rows row, row + 1
             f32x2 b = mk2(Pm[row], Pm[row + 1]);
             f32x2 o0 = mk2(y0[0], y0[1]), o1 = mk2(y1[0], y1[1]);
             if (a.bias) { o0 = o0 + b; o1 = o1 + b; }
             if (a.psn_a) {
-                const f32x2 pa = mk2(Pm[2 * WN_BN + row], Pm[2 * WN_BN + row + 1]), pb = mk2(Pm[3 * WN_BN + row], Pm[3 * WN_BN + row + 1]);
+                const f32x2 pa = mk2(Pm[2 * BN + row], Pm[2 * BN + row + 1]), pb = mk2(Pm[3 * BN + row], Pm[3 * BN + row + 1]);
                 o0 = snake_beta2(o0, pa, pb);
                 o1 = snake_beta2(o1, pa, pb);
             }
             float *yr = yu + (long)(n0 + row) * a.y_cs + p;
             if (ok0) { yr[0] = o0.x; yr[a.y_cs] = o0.y; }
             if (ok1) { yr[D] = o1.x; yr[a.y_cs + D] = o1.y; }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------------------
+// POINT-SPLIT form of the F(2,7) convolution: wino_ps_kernel<D, RT, FUSE>.
+//
+// On gfx950 the fp32 MFMAs run on the SIMD's fp32 vector ALUs: every fp32 VALU instruction of any wave on the SIMD takes its
+// ~4 cycles out of the matrix pipe's time, however many waves there are to "hide" it (tools/ubench/mfma_valu2.hip: 64.7
+// cycles per MFMA alone, 78.6 with 4 VALU instructions beside it, 90.5 with 8 -- at 1, 2 or 4 waves per SIMD alike).  What
+// the input transform costs is therefore its instruction count per MFMA: 24 per 8 MFMAs in wino_conv7_kernel's default shape.
+// Here a wave owns only FOUR of the eight interpolation points, for RT row tiles of 32 output channels: waves 0-3 (one per
+// tile group of 32 tiles) the points 0, +1, -1, inf, waves 4-7 the points +2, -2, +1/2, -1/2.  Each transforms its inputs for
+// its own points only (12 instructions) and feeds 4 RT MFMAs with them: 1.5 VALU instructions per MFMA at RT = 2, 1.0 at
+// RT = 3, with two waves per SIMD (4 RT x 16 accumulator registers each).  The output transform is linear in the M_k, so
+// every wave reduces its four products to partial sums of y[p] and y[p + D]; the two waves of a tile group swap one of the
+// two through LDS (the staging buffers, idle by then) and finish one output position each:
+//     waves 0-3:  y[p]     = (M0 + M1 + M2)           + [ M3 + M4 + M5 + M6 ]            <- from wave + 4
+//     waves 4-7:  y[p + D] = 2 (M3 - M4) + (M5 - M6)/2 + [ M1 - M2 + M7 ]                <- from wave - 4
+// The weight tiles arrive in LDS already in that point order (the DMA's source addresses do the permutation).
+//
+// FUSE (RT = 3, N = Cin = 96: the residual units of the last decoder block): the workgroup holds ALL output channels of its
+// positions, so the unit's second half runs in the same kernel as in conv_gemm_kernel<3, true>: H = snake2(y + b1) in
+// registers is the B operand of the 1x1 conv (weights W2 staged whole, 36 KB), + b2 + residual, store; optionally
+// snake_next(out) beside it (y2), because this kernel's own input must come activated (it is fetched by DMA).
+template <int D, int RT>
+struct PsGeom {
+    static constexpr int NTH = 512;
+    static constexpr int BN = 32 * RT;
+    static constexpr int XW = (257 + 10 * D + 3) & ~3;
+    static constexpr int XP = (WN_BK * (XW / 4) + NTH - 1) / NTH;
+    static constexpr int XBUF = WN_BK * XW;
+    static constexpr int WF4 = WN_PTS * WN_BK * BN / 4;                   // float4 of one block's weight tiles: a multiple of NTH
+    static constexpr int WP = WF4 / NTH;
+    static constexpr int WBUF = WN_PTS * WN_BK * BN;
+    static constexpr int EX = 8 * RT * 16 * 64;                           // floats of the partial-sum exchange: [wave][RT * 16][lane]
+    static constexpr int W2F = BN * BN;                                   // FUSE: the 1x1 conv's weights [k][BN]
+    static constexpr int W2P = (W2F / 4 + NTH - 1) / NTH;
+    static constexpr int STAGE = 2 * XBUF + 2 * WBUF;
+    static constexpr int WORK(bool fuse) { return STAGE > EX + (fuse ? W2F : 0) ? STAGE : EX + (fuse ? W2F : 0); }
+};
+
+template <int D, int RT, bool FUSE>
+__global__ __launch_bounds__(512, 1) void wino_ps_kernel(ConvGemmArgs a, int wg_per_unit, int n_tiles) {
+    using GEO = PsGeom<D, RT>;
+    constexpr int NTH = GEO::NTH, BN = GEO::BN, XW = GEO::XW, XP = GEO::XP, XBUF = GEO::XBUF, WP = GEO::WP, WBUF = GEO::WBUF, xw4 = XW / 4;
+    constexpr int PMF = FUSE ? 6 : 4;
+    extern __shared__ __attribute__((aligned(16))) float smem_all[];
+    float *Pm = smem_all;                                   // per-row parameters (device_common.h: fill_param_table)
+    float *Xs = smem_all + PMF * BN;                        // [2][XBUF]: raw (already activated) input window, rows of XW floats
+    float *Ws = Xs + 2 * XBUF;                              // [2][8 point slots][16][BN]
+
+    int nwg = gridDim.x, orig = blockIdx.x;                 // XCD-aware remap, as conv_gemm_kernel
+    int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+    int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    const int nt = id % n_tiles;
+    const int pt = id / n_tiles;
+    const int unit = pt / wg_per_unit;
+    const int T0 = (pt - unit * wg_per_unit) * WN_NT;
+    const int n0 = nt * BN;
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const float *xu = a.x + (long)unit * a.x_us;
+    const int CinP = ((a.Cin + 31) / 32) * 32;
+    const int ncb = a.Cin / WN_BK;
+    const int tw = wave & 3, pg = wave >> 2;                // tile group, point group
+
+    const int p0 = 2 * D * (T0 / D) + T0 % D;
+    const int pwin0 = (p0 - 6 * D) & ~3;
+    const int T = T0 + tw * 32 + l31;
+    const int tq = T / D, tph = T - tq * D;
+    const int p = 2 * D * tq + tph;                         // this lane's tile: outputs p and p + D
+    const int xoff = p - 6 * D - pwin0;
+
+    fill_param_table<BN, FUSE>(a, Pm, n0, tid, NTH);        // (ordinary loads: all before the first LDS-DMA)
+
+    f32x16 acc[4][RT];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int i = 0; i < RT; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[k][i][r] = 0.0f;
+
+    // staging by LDS-DMA as in wino_conv7_kernel (zero page for the causal left padding; nothing to mask on the right)
+    const int xlim = ((a.Lin + 3) & ~3) - 4;
+    unsigned xo[XP], zsrc = 0, wo[WP];
+#pragma unroll
+    for (int j = 0; j < XP; j++) {
+        const int i = tid + NTH * j;
+        int row = i / xw4;
+        const int c4 = i - row * xw4;
+        row = row < WN_BK ? row : 0;
+        int pos = pwin0 + 4 * c4;
+        zsrc |= pos < 0 ? (1u << j) : 0u;
+        pos = pos < 0 ? 0 : (pos > xlim ? xlim : pos);
+        xo[j] = (unsigned)row * (unsigned)a.x_cs + (unsigned)pos;
+    }
+#pragma unroll
+    for (int k = 0; k < WP; k++) {                           // float4 index tid + NTH k of the [8 slots][16][BN] image
+        const int i = tid + NTH * k, slot = i / (4 * BN), rem = i - slot * (4 * BN), r = rem / (BN / 4), c4 = rem - r * (BN / 4);
+        const int point = slot < 3 ? slot : (slot == 3 ? 7 : slot - 1);           // slots: 0 +1 -1 inf | +2 -2 +1/2 -1/2
+        wo[k] = ((unsigned)point * (unsigned)CinP + (unsigned)r) * (unsigned)a.NP + (unsigned)c4 * 4u;
+    }
+    auto stage = [&](int cb, int buf) {
+        const float *xb = xu + (long)cb * WN_BK * a.x_cs;
+        float *xd = Xs + buf * XBUF + wave * 256;
+#pragma unroll
+        for (int j = 0; j < XP; j++) {
+            const float *src = (zsrc >> j) & 1u ? a.zeros : xb + xo[j];
+            if (NTH * (j + 1) <= WN_BK * xw4 || tid + NTH * j < WN_BK * xw4) wn_dma16(src, xd + j * (NTH * 4));
+        }
+        const float *wb = a.ww + ((long)cb * WN_BK) * a.NP + n0;
+        float *wd = Ws + buf * WBUF + wave * 256;
+#pragma unroll
+        for (int k = 0; k < WP; k++) wn_dma16(wb + wo[k], wd + k * (NTH * 4));
+    };
+
+    // The K loop, specialised per point group (a wave-uniform choice made once, outside the loop).
+    auto main_loop = [&](auto pgc) {
+        constexpr int PG = decltype(pgc)::value;
+        for (int cb = 0; cb < ncb; cb++) {
+            const int buf = cb & 1;
+            if (!(PS_ABL & 8) && cb + 1 < ncb) stage(cb + 1, buf ^ 1);
+            {
+                const float *xs = Xs + buf * XBUF + xoff;
+                const float *ws = Ws + buf * WBUF + PG * (4 * WN_BK * BN) + l31;
+                float dv[3][8], vv[2][4], av[2][4][RT];
+                auto load_d = [&](int kk, int sl) {
+                    const float *xk = xs + (2 * kk + h) * XW;
+#pragma unroll
+                    for (int i = (PG ? 1 : 0); i < (PG ? 7 : 8); i++) dv[sl][i] = (PS_ABL & 2) ? (float)(kk + i) : xk[i * D];     // (the +-2, +-1/2 points do not see d0, d7)
+                };
+                auto load_a = [&](int kk, int sl) {
+                    const float *wk = ws + (2 * kk + h) * BN;
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+#pragma unroll
+                        for (int i = 0; i < RT; i++) av[sl][q][i] = (PS_ABL & 4) ? (float)(q + i + kk) : wk[q * (WN_BK * BN) + 32 * i];
+                };
+                auto transform = [&](int ds, int vs) {      // 12 VALU instructions either way
+                    const float *d = dv[ds];
+                    if constexpr ((PS_ABL & 1) != 0) {
+#pragma unroll
+                        for (int q = 0; q < 4; q++) vv[vs][q] = d[q + 1];
+                    } else if constexpr (PG == 0) {
+                        const float e12 = fmaf(-4.25f, d[4], d[2] + d[6]), o12 = fmaf(-4.25f, d[3], d[1] + d[5]);
+                        vv[vs][0] = fmaf(5.25f, d[4] - d[2], d[0] - d[6]);
+                        vv[vs][1] = e12 + o12;
+                        vv[vs][2] = e12 - o12;
+                        vv[vs][3] = fmaf(5.25f, d[3] - d[5], d[7] - d[1]);
+                    } else {
+                        const float e34 = fmaf(0.25f, d[2], fmaf(-1.25f, d[4], d[6])), o34 = fmaf(4.0f, d[5], fmaf(-5.0f, d[3], d[1]));
+                        const float e56 = fmaf(4.0f, d[2], fmaf(-5.0f, d[4], d[6])), o56 = fmaf(0.25f, d[5], fmaf(-1.25f, d[3], d[1]));
+                        vv[vs][0] = fmaf(0.5f, o34, e34);
+                        vv[vs][1] = fmaf(-0.5f, o34, e34);
+                        vv[vs][2] = fmaf(2.0f, o56, e56);
+                        vv[vs][3] = fmaf(-2.0f, o56, e56);
+                    }
+                };
+                load_d(0, 0);
+                load_a(0, 0);
+                load_d(1, 1);
+                transform(0, 0);
+#pragma unroll
+                for (int kk = 0; kk < WN_BK / 2; kk++) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (kk + 1 < WN_BK / 2) load_a(kk + 1, (kk + 1) & 1);
+                    if (kk + 2 < WN_BK / 2) load_d(kk + 2, (kk + 2) % 3);
+                    if (kk + 1 < WN_BK / 2) transform((kk + 1) % 3, (kk + 1) & 1);
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+#pragma unroll
+                        for (int i = 0; i < RT; i++)
+                            acc[q][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk & 1][q][i], vv[kk & 1][q], acc[q][i], 0, 0, 0);
+#pragma unroll
+                    for (int g = 0; g < 4 * RT; g++) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, RT == 2 ? 2 : 1, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (!(PS_ABL & 16)) asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+    };
+
+    __syncthreads();                                         // tables written (no DMA in flight yet)
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (pg == 0) main_loop(std::integral_constant<int, 0>{});
+    else main_loop(std::integral_constant<int, 1>{});
+
+    // ---- the staging buffers are idle (the loop ended with a barrier): partial output transforms, exchange, finish
+    float *Ex = Xs;                                          // [8 waves][RT * 16][64 lanes]
+    float *W2s = Xs + GEO::EX;                               // FUSE: [BN k rows][BN]
+    if constexpr (FUSE) {
+#pragma unroll
+        for (int j = 0; j < GEO::W2P; j++) {
+            const int i = tid + NTH * j;
+            if (NTH * (j + 1) <= GEO::W2F / 4 || i < GEO::W2F / 4) wn_dma16(a.w2 + 4 * (long)i, W2s + wave * 256 + j * (NTH * 4));
+        }
+    }
+    float yv[RT][16];
+    {
+        float *exw = Ex + (wave * RT * 16) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < RT; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const float m0 = acc[0][i][r], m1 = acc[1][i][r], m2 = acc[2][i][r], m3 = acc[3][i][r];
+                // waves 0-3 hold M0 M1 M2 M7, waves 4-7 M3 M4 M5 M6
+                const float mine = pg == 0 ? (m1 + m2) + m0 : fmaf(2.0f, m0 - m1, 0.5f * (m2 - m3));
+                const float send = pg == 0 ? (m1 - m2) + m3 : (m0 + m1) + (m2 + m3);
+                yv[i][r] = mine;
+                exw[(i * 16 + r) * 64] = send;
+            }
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    {
+        const float *exr = Ex + ((wave ^ 4) * RT * 16) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < RT; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) yv[i][r] += exr[(i * 16 + r) * 64];
+    }
+    const int pos = p + pg * D;                              // this wave finishes y[p] (waves 0-3) or y[p + D] (waves 4-7)
+    const bool ok = pos < a.M;
+    float *yu = a.y + (long)unit * a.y_us;
+
+    if constexpr (!FUSE) {
+#pragma unroll
+        for (int i = 0; i < RT; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;          // rows row, row + 1
+                f32x2 o = mk2(yv[i][r], yv[i][r + 1]);
+                if (a.bias) o = o + mk2(Pm[row], Pm[row + 1]);
+                if (a.psn_a) o = snake_beta2(o, mk2(Pm[2 * BN + row], Pm[2 * BN + row + 1]), mk2(Pm[3 * BN + row], Pm[3 * BN + row + 1]));
+                float *yr = yu + (long)(n0 + row) * a.y_cs + pos;
+                if (ok) { yr[0] = o.x; yr[a.y_cs] = o.y; }
+            }
+    } else {
+        // residual x[row][pos] of all BN rows: fetched now, used after the second product
+        float resv[RT][16];
+        {
+            const float *rup = a.res + (long)unit * a.y_us + (ok ? pos : 0);
+#pragma unroll
+            for (int i = 0; i < RT; i++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) resv[i][r] = rup[(long)(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * a.y_cs];
+        }
+        // H = snake2(y + b1): the second product's B operand; register r of tile i is channel i*32 + (r&3) + 8*(r>>2) + 4h
+#pragma unroll
+        for (int i = 0; i < RT; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const int n = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const f32x2 hv = snake_beta2(mk2(yv[i][r] + Pm[n], yv[i][r + 1] + Pm[n + 1]), mk2(Pm[BN + n], Pm[BN + n + 1]),
+                                             mk2(Pm[2 * BN + n], Pm[2 * BN + n + 1]));
+                yv[i][r] = hv.x;
+                yv[i][r + 1] = hv.y;
+            }
+        float *y2u = a.y2 ? a.y2 + (long)unit * a.y_us : nullptr;
+#pragma unroll
+        for (int o = 0; o < RT; o++) {
+            f32x16 acc2;
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc2[r] = 0.0f;
+            const float *ws2 = W2s + o * 32 + l31 + 4 * h * BN;
+#pragma unroll
+            for (int i = 0; i < RT; i++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int k = i * 32 + (r & 3) + 8 * (r >> 2);                // this lane half's k is k + 4h
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ws2[k * BN], yv[i][r], acc2, 0, 0, 0);
+                    if ((r & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const int n = o * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                f32x2 v = mk2(acc2[r] + Pm[3 * BN + n] + resv[o][r], acc2[r + 1] + Pm[3 * BN + n + 1] + resv[o][r + 1]);
+                float *yr = yu + (long)n * a.y_cs + pos;
+                if (a.psn_a) {
+                    const f32x2 sv = snake_beta2(v, mk2(Pm[4 * BN + n], Pm[4 * BN + n + 1]), mk2(Pm[5 * BN + n], Pm[5 * BN + n + 1]));
+                    if (y2u) {
+                        float *y2r = y2u + (long)n * a.y_cs + pos;
+                        if (ok) { y2r[0] = sv.x; y2r[a.y_cs] = sv.y; }
+                    } else
+                        v = sv;
+                }
+                if (ok) { yr[0] = v.x; yr[a.y_cs] = v.y; }
+            }
         }
     }
 }
@@ -394,12 +742,12 @@ __global__ __launch_bounds__((TconvGeom<RT, RW>::NTH), 1) void wino_tconv_kernel
         float *xd = Xs + buf * XBUF + wave * 256;
 #pragma unroll
         for (int j = 0; j < XP; j++)
-            __builtin_amdgcn_global_load_lds((wn_gptr_t)(xb + xo[j]), (wn_lptr_t)(xd + j * (NTH * 4)), 16, 0, 0);
+            wn_dma16(xb + xo[j], xd + j * (NTH * 4));
         const float *wb = a.ww + ((long)cb * WN_BK) * a.NP + n0;
         float *wd = Ws + buf * WBUF + wave * 256;
 #pragma unroll
         for (int k = 0; k < WP; k++)
-            __builtin_amdgcn_global_load_lds((wn_gptr_t)(wb + wo[k]), (wn_lptr_t)(wd + k * (NTH * 4)), 16, 0, 0);
+            wn_dma16(wb + wo[k], wd + k * (NTH * 4));
     };
 
     __syncthreads();                                         // tables written (no DMA in flight yet)
@@ -531,60 +879,102 @@ static bool wino_tconv_selected(const ConvGemmArgs &a) {
            a.act == ACT_NONE && !a.in_elu && a.s2d <= 1 && a.y && (!a.y2 || a.psn_a) && a.M >= 1 && a.Lin >= 1 && !a.pm && a.S <= 32;
 }
 
+// a whole residual unit of the last decoder block (N = Cin = 96) on wino_ps_kernel<D, 3, true>?
+static bool wino_unit_selected(const ConvGemmArgs &a) {
+    const int d = a.shift_step;
+    return a.ww && a.w2 && !a.wb && a.ntaps == 7 && a.S == 1 && (d == 1 || d == 3 || d == 9) && a.shift0 == -6 * d && a.units >= 1 &&
+           a.N == 96 && a.NP == 96 && a.Cin == 96 && !a.sn_a && a.res && !a.rscale && !a.xb && !a.yb && a.act == ACT_NONE && !a.in_elu &&
+           a.s2d <= 1 && a.M == a.Lin && a.y && a.bias && a.bias2 && a.sn2_a && a.sn2_ib && (!a.y2 || a.psn_a) && (!a.psn_a || a.psn_ib);
+}
+
 bool wino_selected(const ConvGemmArgs &a) {
+    if (wino_unit_selected(a)) return true;
     if (!a.ww || a.wb || a.w2) return false;
     if (wino_tconv_selected(a)) return true;
     const int d = a.shift_step;
     return a.ntaps == 7 && a.S == 1 && (d == 1 || d == 3 || d == 9) && a.shift0 == -6 * d && a.units >= 1 && a.N == a.NP &&
-           a.N % WN_BN == 0 && a.Cin % WN_BK == 0 && !a.res && !a.rscale && !a.y2 && !a.xb && !a.yb && a.act == ACT_NONE && !a.in_elu &&
+           a.N % 64 == 0 && a.Cin % WN_BK == 0 && !a.res && !a.rscale && !a.y2 && !a.xb && !a.yb && a.act == ACT_NONE && !a.in_elu &&
            a.s2d <= 1 && a.M == a.Lin && a.y;
 }
 
 static int wino_rt();
 const char *wino_kernel_name(const ConvGemmArgs &a) {      // as rocprofv3 prints it
+    if (wino_unit_selected(a)) return a.shift_step == 1 ? "wino_ps_kernel<1,3,true>" : a.shift_step == 3 ? "wino_ps_kernel<3,3,true>" : "wino_ps_kernel<9,3,true>";
     if (wino_tconv_selected(a)) {
         const bool big = a.N % 128 == 0;
         if (a.sn_a) return big ? "wino_tconv_kernel<true,2,2>" : "wino_tconv_kernel<true,1,3>";
         return big ? "wino_tconv_kernel<false,2,2>" : "wino_tconv_kernel<false,1,3>";
     }
-    static char names[2][3][2][40];
-    const int di = a.shift_step == 1 ? 0 : a.shift_step == 3 ? 1 : 2, sn = a.sn_a ? 1 : 0, rt = wino_rt();
-    char *n = names[sn][di][rt - 1];
-    if (!n[0]) snprintf(n, 40, "wino_conv7_kernel<%d,%s,%d>", a.shift_step, sn ? "true" : "false", rt);
+    static char names[2][3][4][44];
+    const int di = a.shift_step == 1 ? 0 : a.shift_step == 3 ? 1 : 2, sn = a.sn_a ? 1 : 0, mode = sn && wino_rt() == 3 ? 1 : wino_rt();
+    const int mi = mode == 1 ? 0 : mode == 2 ? 1 : mode == 4 ? 2 : 3;
+    char *n = names[sn][di][mi];
+    if (!n[0]) {
+        if (mode == 3) snprintf(n, 44, "wino_ps_kernel<%d,2,false>", a.shift_step);
+        else snprintf(n, 44, "wino_conv7_kernel<%d,%s,%d,%d>", a.shift_step, sn ? "true" : "false", mode == 2 ? 2 : 1, mode == 1 ? 2 : 1);
+    }
     return n;
 }
 
-// HIPVOC_WINO_RT: row tiles per wave.  Default 1 (8 waves, two per SIMD: the second wave fills part of the first one's
-// per-block prologue and barrier wait; 142.9 ms per 64-unit pass against 145.3 with 2 = one wave per SIMD).
+// HIPVOC_WINO_RT: shape of a workgroup of wino_conv7_kernel<D, SN, RT, RH> (RT row tiles per wave, RH row groups of waves).
+//   1:           RT 1, RH 2 -- 64 rows, 8 waves, two per SIMD
+//   2:           RT 2, RH 1 -- 64 rows, 4 waves, one per SIMD (256 accumulator registers)
+//   4 (default): RT 1, RH 1 -- 32 rows, 4 waves; two INDEPENDENT workgroups per CU, so one's barrier and block prologue
+//                              overlap the other's MFMAs
+//   3:           wino_ps_kernel<D, 2, false>: 64 rows, 8 waves, the eight points split over two waves (no SN form: such
+//                              layers run in shape 1)
 static int wino_rt() {
     static int v = -1;
-    if (v < 0) { const char *e = getenv("HIPVOC_WINO_RT"); v = e && atoi(e) == 2 ? 2 : 1; }
+    if (v < 0) { const char *e = getenv("HIPVOC_WINO_RT"); const int x = e ? atoi(e) : WN_MODE_DEFAULT; v = x == 2 ? 2 : x == 4 ? 4 : x == 3 ? 3 : 1; }
     return v;
 }
 
-template <int D, bool SN, int RT>
+template <int D, bool SN, int RT, int RH>
 static hipError_t wino_launch_one(const ConvGemmArgs &a, hipStream_t s) {
-    using GEO = WinoGeom<D, RT>;
+    using GEO = WinoGeom<D, RT, RH>;
     // tiles of a unit: the pairs (p, p + D) with floor(p / D) even and p < M
     const int n_pairs = (a.M + 2 * D - 1) / (2 * D) * D;
     const int wg_per_unit = (n_pairs + WN_NT - 1) / WN_NT;
-    const int n_tiles = a.N / WN_BN;
+    const int n_tiles = a.N / GEO::BN;
     const long grid = (long)wg_per_unit * a.units * n_tiles;
     if (grid > 0x7fffffffL) return hipErrorInvalidValue;
     // Window bound: a workgroup's tiles T0 .. T0+127 have base positions within 2D (127/D + 1) + D - 1 <= 253 + 3D of the
     // first one, the window starts at most 6D + 3 before it and the last read is D past the base: XW >= 257 + 10 D.
-    const size_t lds = sizeof(float) * (4 * WN_BN + (SN ? 2 * (size_t)a.Cin : 0) + 2 * (size_t)GEO::XBUF + 2 * (size_t)WN_WBUF);
+    const size_t lds = sizeof(float) * (4 * GEO::BN + (SN ? 2 * (size_t)a.Cin : 0) + 2 * (size_t)GEO::XBUF + 2 * (size_t)GEO::WBUF);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     static bool done[64] = {};
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 64 && !done[dev]) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(wino_conv7_kernel<D, SN, RT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(wino_conv7_kernel<D, SN, RT, RH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         done[dev] = true;
     }
-    hipLaunchKernelGGL((wino_conv7_kernel<D, SN, RT>), dim3((unsigned)grid), dim3(GEO::NTH), lds, s, a, wg_per_unit, n_tiles);
+    hipLaunchKernelGGL((wino_conv7_kernel<D, SN, RT, RH>), dim3((unsigned)grid), dim3(GEO::NTH), lds, s, a, wg_per_unit, n_tiles);
+    return hipGetLastError();
+}
+
+template <int D, int RT, bool FUSE>
+static hipError_t wino_ps_launch_one(const ConvGemmArgs &a, hipStream_t s) {
+    using GEO = PsGeom<D, RT>;
+    const int n_pairs = (a.M + 2 * D - 1) / (2 * D) * D;     // tiles of a unit, as wino_launch_one
+    const int wg_per_unit = (n_pairs + WN_NT - 1) / WN_NT;
+    const int n_tiles = a.N / GEO::BN;
+    const long grid = (long)wg_per_unit * a.units * n_tiles;
+    if (grid > 0x7fffffffL) return hipErrorInvalidValue;
+    const size_t lds = sizeof(float) * ((FUSE ? 6 : 4) * GEO::BN + (size_t)GEO::WORK(FUSE));
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    static bool done[64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64 && !done[dev]) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(wino_ps_kernel<D, RT, FUSE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        done[dev] = true;
+    }
+    hipLaunchKernelGGL((wino_ps_kernel<D, RT, FUSE>), dim3((unsigned)grid), dim3(GEO::NTH), lds, s, a, wg_per_unit, n_tiles);
     return hipGetLastError();
 }
 
@@ -619,6 +1009,11 @@ static hipError_t wino_tconv_launch_one(const ConvGemmArgs &a, hipStream_t s) {
 hipError_t launch_wino_conv7(const ConvGemmArgs &a, hipStream_t s) {
     if (!wino_selected(a)) return hipErrorInvalidValue;
     if (a.M <= 0) return hipSuccess;
+    if (!a.zeros) return hipErrorInvalidValue;
+    if (wino_unit_selected(a)) {
+        if ((a.x_cs & 3) || (a.x_us & 3) || ((uintptr_t)a.x & 15) || ((uintptr_t)a.ww & 15) || ((uintptr_t)a.w2 & 15) || a.Lin < 1) return hipErrorInvalidValue;
+        return a.shift_step == 1 ? wino_ps_launch_one<1, 3, true>(a, s) : a.shift_step == 3 ? wino_ps_launch_one<3, 3, true>(a, s) : wino_ps_launch_one<9, 3, true>(a, s);
+    }
     if (wino_tconv_selected(a)) {
         if ((a.x_cs & 3) || (a.x_us & 3) || ((uintptr_t)a.x & 15) || ((uintptr_t)a.ww & 15) || (a.NP & 3) || (a.sn_a && !a.sn_ib) || a.Cin > 4096)
             return hipErrorInvalidValue;
@@ -631,14 +1026,17 @@ hipError_t launch_wino_conv7(const ConvGemmArgs &a, hipStream_t s) {
         (a.sn_a && !a.sn_ib) || a.Cin > 4096)
         return hipErrorInvalidValue;
     const bool sn = a.sn_a != nullptr;
-#define WN_GO(D_) (sn ? (wino_rt() == 1 ? wino_launch_one<D_, true, 1>(a, s) : wino_launch_one<D_, true, 2>(a, s)) \
-                      : (wino_rt() == 1 ? wino_launch_one<D_, false, 1>(a, s) : wino_launch_one<D_, false, 2>(a, s)))
+    const int mode = sn && wino_rt() == 3 ? 1 : wino_rt();
+    if (mode == 3) return a.shift_step == 1 ? wino_ps_launch_one<1, 2, false>(a, s) : a.shift_step == 3 ? wino_ps_launch_one<3, 2, false>(a, s) : wino_ps_launch_one<9, 2, false>(a, s);
+#define WN_GO2(D_, SN_) (mode == 1 ? wino_launch_one<D_, SN_, 1, 2>(a, s) : mode == 2 ? wino_launch_one<D_, SN_, 2, 1>(a, s) : wino_launch_one<D_, SN_, 1, 1>(a, s))
+#define WN_GO(D_) (sn ? WN_GO2(D_, true) : WN_GO2(D_, false))
     switch (a.shift_step) {
         case 1: return WN_GO(1);
         case 3: return WN_GO(3);
         default: return WN_GO(9);
     }
 #undef WN_GO
+#undef WN_GO2
 }
 
 }  // namespace hipvoc

@@ -3,9 +3,10 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 
-// 256 MiB per GPU: one 10 s utterance (two 64-frame units) of the full-size decoder in fp32 / bf16x3, or one unit in the
-// bf16 mode with its packed exchange tensors; many units of smaller topologies.
-#define HIPVOC_SCRATCH_BYTES (256u << 20)
+// 384 MiB per GPU: one 10 s utterance (two 64-frame units) of the full-size decoder in fp32 (185 MiB per unit: three
+// ping-pong tensors plus the two activated copies the Winograd kernels read) and bf16, four units in bf16x3; many units of
+// smaller topologies.
+#define HIPVOC_SCRATCH_BYTES (384u << 20)
 #define HIPVOC_SCRATCH_MAX_DEVICES 64
 
 namespace hipvoc {

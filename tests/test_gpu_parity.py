@@ -330,7 +330,7 @@ def test_gemm1_bitwise(pkg, synth, cfg_name, unit, frames, monkeypatch):
 
 
 def test_winograd_conv7_against_the_direct_kernels(pkg, synth, vo, monkeypatch):
-    """fp32 k = 7 convs of decoder[0] and blocks 0-2 run as Winograd F(2,7) on the matrix cores (kernels_wino.hip): fewer
+    """fp32 k = 7 convs of decoder[0] and all four blocks run as Winograd F(2,7) on the matrix cores (kernels_wino.hip): fewer
     multiplications, different rounding.  With it off (HIPVOC_WINO=0) the direct implicit-GEMM kernels run instead.  Both
     must meet the fp32 gates against the oracle on a 10 s utterance (edge tiles: the 61-frame tail, every dilation), the
     two waveforms must agree far inside the gate, and the Winograd kernels must really be the ones that ran."""
@@ -345,11 +345,11 @@ def test_winograd_conv7_against_the_direct_kernels(pkg, synth, vo, monkeypatch):
         v = pkg.HipVocoder.load(path, device=0, unit_frames=64)
         v.set_profile(True)
         out[wino] = v.synthesize(codes)
-        used = sorted(k for k in v.last_profile() if "wino_conv7_kernel" in k)
+        used = sorted(k for k in v.last_profile() if "wino_conv7_kernel" in k or "wino_ps_kernel" in k)
         assert bool(used) == (wino == "1"), used
         if wino == "1":
             steps = {k.split("|")[0] for k in used}
-            assert steps == {"dec0_conv7", "b0_conv7", "b1_conv7", "b2_conv7"}, steps
+            assert steps == {"dec0_conv7", "b0_conv7", "b1_conv7", "b2_conv7", "b3_resunit"}, steps    # b3: whole units (wino_ps_kernel<D,3,true>)
             assert {k.split("<")[1].split(",")[0] for k in used} == {"1", "3", "9"}          # every dilation
         err = float(np.abs(out[wino] - ref).max())
         assert err <= WAV_MAX_ABS and snr_db(ref, out[wino]) >= WAV_SNR_DB, (wino, err, snr_db(ref, out[wino]))

@@ -73,7 +73,7 @@ def test_noalloc_full_size_two_calls_second_smaller(pkg, synth):
     ref1, got1 = _both(v, _units(synth, cfg, 1, 64, 2000))
     assert np.array_equal(ref1.view(np.uint32), got1.view(np.uint32))
     assert np.abs(ref1).max() <= 1.0 and ref1.std() > 0.02
-    # a pass that does not fit the 256 MiB array is refused before anything is launched, and the handle keeps serving
+    # a pass that does not fit the 384 MiB array is refused before anything is launched, and the handle keeps serving
     import ctypes as C
     stride = (v.unit_samples + 63) // 64 * 64
     d_codes = torch.zeros((3, 64, 16), dtype=torch.int64, device="cuda")
