@@ -101,6 +101,12 @@ __device__ __forceinline__ void wn_dma16(const float *g, float *lds) {
     __builtin_amdgcn_global_load_lds((wn_gptr_t)g, (wn_lptr_t)lds, 16, 0, 0);
 #endif
 }
+// ... the same with the address as a wave-uniform base (SGPR pair) + a per-lane byte offset: the per-block address arithmetic
+// stays on the scalar unit (a 64-bit VALU add per piece is matrix-pipe time on this chip, see wino_ps_kernel's header)
+__device__ __forceinline__ void wn_dma16_s(const float *sbase, unsigned voff_bytes, float *lds) {
+    const unsigned l = (unsigned)(size_t)(wn_lptr_t)lds;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(l), "v"(voff_bytes), "s"(sbase) : "memory");
+}
 
 // SN: the conv has a SnakeBeta prologue (a.sn_a / a.sn_ib), applied to the inputs as they are read from LDS
 template <int D, bool SN, int RT, int RH>
@@ -133,6 +139,7 @@ __global__ __launch_bounds__((WinoGeom<D, RT, RH>::NTH), (RT * RH == 1 ? 2 : 1))
     // window of raw activations this workgroup needs: positions [pwin0, pwin0 + XW)
     const int p0 = 2 * D * (T0 / D) + T0 % D;
     const int pwin0 = (p0 - 6 * D) & ~3;                    // (floor to a multiple of 4, also when negative)
+    const bool wg_zero = pwin0 < 0;                          // (workgroup-uniform) some pieces of the window lie left of the unit
     // this lane's tile: outputs p and p + D from the inputs p - 6D + i D, i = 0..7
     const int tw = wave & 3, rh = wave >> 2;                    // tile group of this wave, its row group (RT row tiles)
     const int T = T0 + tw * 32 + l31;
@@ -196,14 +203,16 @@ __global__ __launch_bounds__((WinoGeom<D, RT, RH>::NTH), (RT * RH == 1 ? 2 : 1))
         float *xd = Xs + buf * XBUF + wave * 256;
 #pragma unroll
         for (int j = 0; j < XP; j++) {
-            const float *src = (WN_ZP && ((zsrc >> j) & 1u)) ? a.zeros : xb + xo[j];
-            if (NTH * (j + 1) <= WN_BK * xw4 || tid + NTH * j < WN_BK * xw4) wn_dma16(src, xd + j * (NTH * 4));
+            if (NTH * (j + 1) <= WN_BK * xw4 || tid + NTH * j < WN_BK * xw4) {
+                if (wg_zero) wn_dma16((WN_ZP && ((zsrc >> j) & 1u)) ? a.zeros : xb + xo[j], xd + j * (NTH * 4));
+                else wn_dma16_s(xb, xo[j] * 4u, xd + j * (NTH * 4));
+            }
         }
         const float *wb = a.ww + ((long)cb * WN_BK) * a.NP + n0;
         float *wd = Ws + buf * WN_WBUF + wave * 256;
 #pragma unroll
         for (int k = 0; k < WP; k++)
-            wn_dma16(wb + wo[k], wd + k * (NTH * 4));
+            wn_dma16_s(wb, wo[k] * 4u, wd + k * (NTH * 4));
     };
 
     __syncthreads();                                         // tables written (no DMA in flight yet)
@@ -411,6 +420,7 @@ __global__ __launch_bounds__(512, 1) void wino_ps_kernel(ConvGemmArgs a, int wg_
 
     const int p0 = 2 * D * (T0 / D) + T0 % D;
     const int pwin0 = (p0 - 6 * D) & ~3;
+    const bool wg_zero = pwin0 < 0;                          // (workgroup-uniform) some pieces of the window lie left of the unit
     const int T = T0 + tw * 32 + l31;
     const int tq = T / D, tph = T - tq * D;
     const int p = 2 * D * tq + tph;                         // this lane's tile: outputs p and p + D
@@ -451,13 +461,15 @@ __global__ __launch_bounds__(512, 1) void wino_ps_kernel(ConvGemmArgs a, int wg_
         float *xd = Xs + buf * XBUF + wave * 256;
 #pragma unroll
         for (int j = 0; j < XP; j++) {
-            const float *src = (zsrc >> j) & 1u ? a.zeros : xb + xo[j];
-            if (NTH * (j + 1) <= WN_BK * xw4 || tid + NTH * j < WN_BK * xw4) wn_dma16(src, xd + j * (NTH * 4));
+            if (NTH * (j + 1) <= WN_BK * xw4 || tid + NTH * j < WN_BK * xw4) {
+                if (wg_zero) wn_dma16((zsrc >> j) & 1u ? a.zeros : xb + xo[j], xd + j * (NTH * 4));
+                else wn_dma16_s(xb, xo[j] * 4u, xd + j * (NTH * 4));
+            }
         }
         const float *wb = a.ww + ((long)cb * WN_BK) * a.NP + n0;
         float *wd = Ws + buf * WBUF + wave * 256;
 #pragma unroll
-        for (int k = 0; k < WP; k++) wn_dma16(wb + wo[k], wd + k * (NTH * 4));
+        for (int k = 0; k < WP; k++) wn_dma16_s(wb, wo[k] * 4u, wd + k * (NTH * 4));
     };
 
     // The K loop, specialised per point group (a wave-uniform choice made once, outside the loop).
@@ -549,19 +561,43 @@ __global__ __launch_bounds__(512, 1) void wino_ps_kernel(ConvGemmArgs a, int wg_
     float yv[RT][16];
     {
         float *exw = Ex + (wave * RT * 16) * 64 + lane;
+        if (pg == 0) {                                       // M0 M1 M2 M7 here: keep M0 + M1 + M2, send M1 - M2 + M7
+#pragma unroll
+            for (int i = 0; i < RT; i++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const float m0 = acc[0][i][r], m1 = acc[1][i][r], m2 = acc[2][i][r], m3 = acc[3][i][r];
+                    yv[i][r] = (m1 + m2) + m0;
+                    exw[(i * 16 + r) * 64] = (m1 - m2) + m3;
+                }
+        } else {                                             // M3 M4 M5 M6 here: keep 2 (M3 - M4) + (M5 - M6) / 2, send their sum
+#pragma unroll
+            for (int i = 0; i < RT; i++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const float m0 = acc[0][i][r], m1 = acc[1][i][r], m2 = acc[2][i][r], m3 = acc[3][i][r];
+                    yv[i][r] = fmaf(2.0f, m0 - m1, 0.5f * (m2 - m3));
+                    exw[(i * 16 + r) * 64] = (m0 + m1) + (m2 + m3);
+                }
+        }
+    }
+    const int pos = p + pg * D;                              // this wave finishes y[p] (waves 0-3) or y[p + D] (waves 4-7)
+    const bool ok = pos < a.M;
+    // FUSE: the residual x[row][pos] of all BN rows is requested BEFORE the exchange barrier (the accumulators are dead, the
+    // registers free) and used after the second product.  vmcnt retires in order and the W2 pieces were issued first, so the
+    // barrier waits for those only: vmcnt(RT * 16) leaves the residual loads in flight.
+    float resv[FUSE ? RT : 1][16];
+    if constexpr (FUSE) {
+        const float *rup = a.res + (long)unit * a.y_us + (ok ? pos : 0);
 #pragma unroll
         for (int i = 0; i < RT; i++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const float m0 = acc[0][i][r], m1 = acc[1][i][r], m2 = acc[2][i][r], m3 = acc[3][i][r];
-                // waves 0-3 hold M0 M1 M2 M7, waves 4-7 M3 M4 M5 M6
-                const float mine = pg == 0 ? (m1 + m2) + m0 : fmaf(2.0f, m0 - m1, 0.5f * (m2 - m3));
-                const float send = pg == 0 ? (m1 - m2) + m3 : (m0 + m1) + (m2 + m3);
-                yv[i][r] = mine;
-                exw[(i * 16 + r) * 64] = send;
-            }
+            for (int r = 0; r < 16; r++) resv[i][r] = rup[(long)(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * a.y_cs];
+        static_assert(RT * 16 <= 63, "vmcnt range");
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(RT * 16) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     {
         const float *exr = Ex + ((wave ^ 4) * RT * 16) * 64 + lane;
 #pragma unroll
@@ -569,8 +605,6 @@ __global__ __launch_bounds__(512, 1) void wino_ps_kernel(ConvGemmArgs a, int wg_
 #pragma unroll
             for (int r = 0; r < 16; r++) yv[i][r] += exr[(i * 16 + r) * 64];
     }
-    const int pos = p + pg * D;                              // this wave finishes y[p] (waves 0-3) or y[p + D] (waves 4-7)
-    const bool ok = pos < a.M;
     float *yu = a.y + (long)unit * a.y_us;
 
     if constexpr (!FUSE) {
@@ -586,15 +620,6 @@ __global__ __launch_bounds__(512, 1) void wino_ps_kernel(ConvGemmArgs a, int wg_
                 if (ok) { yr[0] = o.x; yr[a.y_cs] = o.y; }
             }
     } else {
-        // residual x[row][pos] of all BN rows: fetched now, used after the second product
-        float resv[RT][16];
-        {
-            const float *rup = a.res + (long)unit * a.y_us + (ok ? pos : 0);
-#pragma unroll
-            for (int i = 0; i < RT; i++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) resv[i][r] = rup[(long)(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * a.y_cs];
-        }
         // H = snake2(y + b1): the second product's B operand; register r of tile i is channel i*32 + (r&3) + 8*(r>>2) + 4h
 #pragma unroll
         for (int i = 0; i < RT; i++)
