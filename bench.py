@@ -351,7 +351,14 @@ def main(argv=None):
                  "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                  "avg_launch_ms": round(kd["ms"] / kd["launches"], 4), "launches_per_pass": kd["launches"],
                  "units_per_pass": G, "share_of_pass_time": round(kd["ms"] / total_ms, 3)}
-            if name.startswith("wino_conv7_kernel"):
+            if name.startswith("wino_ps_kernel") and name.endswith("true>"):
+                # a whole residual unit (conv7 by F(2,7) + the 1x1 conv): of the direct form's 7 + 1 tap-products the matrix
+                # cores execute 4 + 1
+                r["executed_mfma_tflops"] = round(achieved * 5 / 8, 3)
+                r["executed_frac"] = round(achieved * 5 / 8 / peak, 4)
+                r["note"] = ("achieved = algorithmic (direct-form) FLOPs / time; the kernel is a residual unit whose k=7 conv runs as "
+                             "Winograd F(2,7): it executes 5/8 of those multiplications on the matrix cores (executed_*)")
+            elif name.startswith("wino_conv7_kernel") or name.startswith("wino_ps_kernel"):
                 # Winograd F(2,7): 8 multiplications where the direct form (what the algorithmic count assumes) has 14, so
                 # `achieved` can exceed the MFMA peak; the matrix cores execute 4/7 of it
                 r["executed_mfma_tflops"] = round(achieved * 4 / 7, 3)

@@ -25,6 +25,9 @@ __global__ __launch_bounds__(NTH, 1) void k(float *out, int iters, float seed) {
                 if (K == 0) v[i] = fmaf(v[i], b, a);
                 if (K == 1) u[i] = u[i] + (unsigned)it;
                 if (K == 2) v[i] = (u[i] >> (it & 31)) & 1 ? v[i] : a;
+                if (K == 3) v[i] = __builtin_amdgcn_sinf(v[i]);
+                if (K == 4) v[i] = __builtin_amdgcn_rcpf(v[i]);
+                if (K == 5) v[i] = __builtin_amdgcn_exp2f(v[i]);
             }
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, K == 2 ? 3 * NV : NV, 0);
@@ -64,6 +67,7 @@ int main() {
     run<0, 0, 8, 512>("fma"); run<2, 0, 8, 512>("fma"); run<4, 0, 8, 512>("fma"); run<8, 0, 8, 512>("fma");
     run<4, 1, 8, 512>("addu32"); run<8, 1, 8, 512>("addu32");
     run<4, 2, 8, 512>("shift+and+cndmask"); 
+    run<2, 3, 8, 512>("v_sin"); run<4, 3, 8, 512>("v_sin"); run<8, 3, 8, 512>("v_sin"); run<4, 4, 8, 512>("v_rcp"); run<4, 5, 8, 512>("v_exp");
     run<0, 0, 4, 1024>("fma"); run<4, 0, 4, 1024>("fma"); run<8, 0, 4, 1024>("fma");
     return 0;
 }
