@@ -59,7 +59,7 @@ static constexpr int WN_PTS = 8;
 #define WN_ASMDMA 1
 #endif
 #ifndef WN_MODE_DEFAULT
-#define WN_MODE_DEFAULT 4
+#define WN_MODE_DEFAULT 5
 #endif
 #ifndef WN_KATTR
 #define WN_KATTR
@@ -157,15 +157,6 @@ __global__ __launch_bounds__((WinoGeom<D, RT, RH>::NTH), (RT * RH == 1 ? 2 : 1))
     // below).  RIGHT of the unit (positions >= Lin = M): the only input of a tile that can lie there while the tile's first
     // output p is stored is x[p + D], which enters V7 alone, and M7 enters y1 = y[p + D] alone -- an output that is not stored.
     // So whatever the (clamped, finite) fetch delivers there never reaches memory, and the loop needs no per-lane masks.
-    // ---- parameter tables: ordinary loads, all BEFORE the first LDS-DMA (hipcc drains every DMA in flight at the next
-    // use of an ordinary load's result)
-    fill_param_table<BN, false>(a, Pm, n0, tid, NTH);
-    if constexpr (SN) {
-        for (int c = tid; c < a.Cin; c += NTH) {
-            Sp[2 * c] = a.sn_a[c];
-            Sp[2 * c + 1] = a.sn_ib[c];
-        }
-    }
 
     f32x16 acc[WN_PTS][RT];
 #pragma unroll
@@ -215,8 +206,16 @@ __global__ __launch_bounds__((WinoGeom<D, RT, RH>::NTH), (RT * RH == 1 ? 2 : 1))
             wn_dma16_s(wb, wo[k] * 4u, wd + k * (NTH * 4));
     };
 
-    __syncthreads();                                         // tables written (no DMA in flight yet)
+    // the first block's DMA goes out first; the parameter tables (ordinary loads, then LDS writes) are filled while it flies
+    // (the DMA is inline asm, so the compiler does not drain it at the first use of an ordinary load's result)
     stage(0, 0);
+    fill_param_table<BN, false>(a, Pm, n0, tid, NTH);
+    if constexpr (SN) {
+        for (int c = tid; c < a.Cin; c += NTH) {
+            Sp[2 * c] = a.sn_a[c];
+            Sp[2 * c + 1] = a.sn_ib[c];
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     for (int cb = 0; cb < ncb; cb++) {
         const int buf = cb & 1;
@@ -375,26 +374,28 @@ __global__ __launch_bounds__((WinoGeom<D, RT, RH>::NTH), (RT * RH == 1 ? 2 : 1))
 // positions, so the unit's second half runs in the same kernel as in conv_gemm_kernel<3, true>: H = snake2(y + b1) in
 // registers is the B operand of the 1x1 conv (weights W2 staged whole, 36 KB), + b2 + residual, store; optionally
 // snake_next(out) beside it (y2), because this kernel's own input must come activated (it is fetched by DMA).
-template <int D, int RT>
+template <int D, int RT, int NTG, int BK>
 struct PsGeom {
-    static constexpr int NTH = 512;
+    static constexpr int NTH = 2 * NTG * 64;                              // NTG tile groups x 2 point groups of waves
+    static constexpr int NT = 32 * NTG;                                   // tiles per workgroup
     static constexpr int BN = 32 * RT;
-    static constexpr int XW = (257 + 10 * D + 3) & ~3;
-    static constexpr int XP = (WN_BK * (XW / 4) + NTH - 1) / NTH;
-    static constexpr int XBUF = WN_BK * XW;
-    static constexpr int WF4 = WN_PTS * WN_BK * BN / 4;                   // float4 of one block's weight tiles: a multiple of NTH
+    static constexpr int XW = (2 * NT + 1 + 10 * D + 3) & ~3;             // window bound as in wino_launch_one
+    static constexpr int XP = (BK * (XW / 4) + NTH - 1) / NTH;
+    static constexpr int XBUF = BK * XW;
+    static constexpr int WF4 = WN_PTS * BK * BN / 4;                      // float4 of one block's weight tiles: a multiple of NTH
     static constexpr int WP = WF4 / NTH;
-    static constexpr int WBUF = WN_PTS * WN_BK * BN;
-    static constexpr int EX = 8 * RT * 16 * 64;                           // floats of the partial-sum exchange: [wave][RT * 16][lane]
+    static constexpr int WBUF = WN_PTS * BK * BN;
+    static constexpr int EX = 2 * NTG * RT * 16 * 64;                     // floats of the partial-sum exchange: [wave][RT * 16][lane]
     static constexpr int W2F = BN * BN;                                   // FUSE: the 1x1 conv's weights [k][BN]
     static constexpr int W2P = (W2F / 4 + NTH - 1) / NTH;
     static constexpr int STAGE = 2 * XBUF + 2 * WBUF;
     static constexpr int WORK(bool fuse) { return STAGE > EX + (fuse ? W2F : 0) ? STAGE : EX + (fuse ? W2F : 0); }
+    static_assert(WF4 % NTH == 0 && (NTG == 2 || NTG == 4) && BK % 2 == 0, "geometry");
 };
 
-template <int D, int RT, bool FUSE>
-__global__ __launch_bounds__(512, 1) void wino_ps_kernel(ConvGemmArgs a, int wg_per_unit, int n_tiles) {
-    using GEO = PsGeom<D, RT>;
+template <int D, int RT, bool FUSE, int NTG, int BK>
+__global__ __launch_bounds__((PsGeom<D, RT, NTG, BK>::NTH), (NTG == 2 ? 2 : 1)) void wino_ps_kernel(ConvGemmArgs a, int wg_per_unit, int n_tiles) {
+    using GEO = PsGeom<D, RT, NTG, BK>;
     constexpr int NTH = GEO::NTH, BN = GEO::BN, XW = GEO::XW, XP = GEO::XP, XBUF = GEO::XBUF, WP = GEO::WP, WBUF = GEO::WBUF, xw4 = XW / 4;
     constexpr int PMF = FUSE ? 6 : 4;
     extern __shared__ __attribute__((aligned(16))) float smem_all[];
@@ -408,15 +409,15 @@ __global__ __launch_bounds__(512, 1) void wino_ps_kernel(ConvGemmArgs a, int wg_
     const int nt = id % n_tiles;
     const int pt = id / n_tiles;
     const int unit = pt / wg_per_unit;
-    const int T0 = (pt - unit * wg_per_unit) * WN_NT;
+    const int T0 = (pt - unit * wg_per_unit) * GEO::NT;
     const int n0 = nt * BN;
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     const float *xu = a.x + (long)unit * a.x_us;
     const int CinP = ((a.Cin + 31) / 32) * 32;
-    const int ncb = a.Cin / WN_BK;
-    const int tw = wave & 3, pg = wave >> 2;                // tile group, point group
+    const int ncb = a.Cin / BK;
+    const int tw = wave & (NTG - 1), pg = wave / NTG;       // tile group, point group
 
     const int p0 = 2 * D * (T0 / D) + T0 % D;
     const int pwin0 = (p0 - 6 * D) & ~3;
@@ -426,7 +427,6 @@ __global__ __launch_bounds__(512, 1) void wino_ps_kernel(ConvGemmArgs a, int wg_
     const int p = 2 * D * tq + tph;                         // this lane's tile: outputs p and p + D
     const int xoff = p - 6 * D - pwin0;
 
-    fill_param_table<BN, FUSE>(a, Pm, n0, tid, NTH);        // (ordinary loads: all before the first LDS-DMA)
 
     f32x16 acc[4][RT];
 #pragma unroll
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(512, 1) void wino_ps_kernel(ConvGemmArgs a, int wg_
         const int i = tid + NTH * j;
         int row = i / xw4;
         const int c4 = i - row * xw4;
-        row = row < WN_BK ? row : 0;
+        row = row < BK ? row : 0;
         int pos = pwin0 + 4 * c4;
         zsrc |= pos < 0 ? (1u << j) : 0u;
         pos = pos < 0 ? 0 : (pos > xlim ? xlim : pos);
@@ -452,21 +452,21 @@ __global__ __launch_bounds__(512, 1) void wino_ps_kernel(ConvGemmArgs a, int wg_
     }
 #pragma unroll
     for (int k = 0; k < WP; k++) {                           // float4 index tid + NTH k of the [8 slots][16][BN] image
-        const int i = tid + NTH * k, slot = i / (4 * BN), rem = i - slot * (4 * BN), r = rem / (BN / 4), c4 = rem - r * (BN / 4);
+        const int i = tid + NTH * k, slot = i / (BK * BN / 4), rem = i - slot * (BK * BN / 4), r = rem / (BN / 4), c4 = rem - r * (BN / 4);
         const int point = slot < 3 ? slot : (slot == 3 ? 7 : slot - 1);           // slots: 0 +1 -1 inf | +2 -2 +1/2 -1/2
         wo[k] = ((unsigned)point * (unsigned)CinP + (unsigned)r) * (unsigned)a.NP + (unsigned)c4 * 4u;
     }
     auto stage = [&](int cb, int buf) {
-        const float *xb = xu + (long)cb * WN_BK * a.x_cs;
+        const float *xb = xu + (long)cb * BK * a.x_cs;
         float *xd = Xs + buf * XBUF + wave * 256;
 #pragma unroll
         for (int j = 0; j < XP; j++) {
-            if (NTH * (j + 1) <= WN_BK * xw4 || tid + NTH * j < WN_BK * xw4) {
+            if (NTH * (j + 1) <= BK * xw4 || tid + NTH * j < BK * xw4) {
                 if (wg_zero) wn_dma16((zsrc >> j) & 1u ? a.zeros : xb + xo[j], xd + j * (NTH * 4));
                 else wn_dma16_s(xb, xo[j] * 4u, xd + j * (NTH * 4));
             }
         }
-        const float *wb = a.ww + ((long)cb * WN_BK) * a.NP + n0;
+        const float *wb = a.ww + ((long)cb * BK) * a.NP + n0;
         float *wd = Ws + buf * WBUF + wave * 256;
 #pragma unroll
         for (int k = 0; k < WP; k++) wn_dma16_s(wb, wo[k] * 4u, wd + k * (NTH * 4));
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(512, 1) void wino_ps_kernel(ConvGemmArgs a, int wg_
             if (!(PS_ABL & 8) && cb + 1 < ncb) stage(cb + 1, buf ^ 1);
             {
                 const float *xs = Xs + buf * XBUF + xoff;
-                const float *ws = Ws + buf * WBUF + PG * (4 * WN_BK * BN) + l31;
+                const float *ws = Ws + buf * WBUF + PG * (4 * BK * BN) + l31;
                 float dv[3][8], vv[2][4], av[2][4][RT];
                 auto load_d = [&](int kk, int sl) {
                     const float *xk = xs + (2 * kk + h) * XW;
@@ -492,7 +492,7 @@ __global__ __launch_bounds__(512, 1) void wino_ps_kernel(ConvGemmArgs a, int wg_
 #pragma unroll
                     for (int q = 0; q < 4; q++)
 #pragma unroll
-                        for (int i = 0; i < RT; i++) av[sl][q][i] = (PS_ABL & 4) ? (float)(q + i + kk) : wk[q * (WN_BK * BN) + 32 * i];
+                        for (int i = 0; i < RT; i++) av[sl][q][i] = (PS_ABL & 4) ? (float)(q + i + kk) : wk[q * (BK * BN) + 32 * i];
                 };
                 auto transform = [&](int ds, int vs) {      // 12 VALU instructions either way
                     const float *d = dv[ds];
@@ -519,11 +519,11 @@ __global__ __launch_bounds__(512, 1) void wino_ps_kernel(ConvGemmArgs a, int wg_
                 load_d(1, 1);
                 transform(0, 0);
 #pragma unroll
-                for (int kk = 0; kk < WN_BK / 2; kk++) {
+                for (int kk = 0; kk < BK / 2; kk++) {
                     __builtin_amdgcn_sched_barrier(0);
-                    if (kk + 1 < WN_BK / 2) load_a(kk + 1, (kk + 1) & 1);
-                    if (kk + 2 < WN_BK / 2) load_d(kk + 2, (kk + 2) % 3);
-                    if (kk + 1 < WN_BK / 2) transform((kk + 1) % 3, (kk + 1) & 1);
+                    if (kk + 1 < BK / 2) load_a(kk + 1, (kk + 1) & 1);
+                    if (kk + 2 < BK / 2) load_d(kk + 2, (kk + 2) % 3);
+                    if (kk + 1 < BK / 2) transform((kk + 1) % 3, (kk + 1) & 1);
 #pragma unroll
                     for (int q = 0; q < 4; q++)
 #pragma unroll
@@ -542,8 +542,8 @@ __global__ __launch_bounds__(512, 1) void wino_ps_kernel(ConvGemmArgs a, int wg_
         }
     };
 
-    __syncthreads();                                         // tables written (no DMA in flight yet)
-    stage(0, 0);
+    stage(0, 0);                                             // (first: the parameter tables are filled while it flies)
+    fill_param_table<BN, FUSE>(a, Pm, n0, tid, NTH);
     asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (pg == 0) main_loop(std::integral_constant<int, 0>{});
     else main_loop(std::integral_constant<int, 1>{});
@@ -599,7 +599,7 @@ __global__ __launch_bounds__(512, 1) void wino_ps_kernel(ConvGemmArgs a, int wg_
         asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
     {
-        const float *exr = Ex + ((wave ^ 4) * RT * 16) * 64 + lane;
+        const float *exr = Ex + ((wave ^ NTG) * RT * 16) * 64 + lane;
 #pragma unroll
         for (int i = 0; i < RT; i++)
 #pragma unroll
@@ -727,13 +727,6 @@ __global__ __launch_bounds__((TconvGeom<RT, RW>::NTH), 1) void wino_tconv_kernel
         dmask |= (pi >= 0 && pi < a.Lin) ? (1u << i) : 0u;
     }
 
-    fill_param_table<BN, false>(a, Pm, n0, tid, NTH);       // (ordinary loads: all before the first LDS-DMA)
-    if constexpr (SN) {
-        for (int c = tid; c < a.Cin; c += NTH) {
-            Sp[2 * c] = a.sn_a[c];
-            Sp[2 * c + 1] = a.sn_ib[c];
-        }
-    }
 
     f32x16 acc[WT_PTS][RT];
 #pragma unroll
@@ -775,8 +768,14 @@ __global__ __launch_bounds__((TconvGeom<RT, RW>::NTH), 1) void wino_tconv_kernel
             wn_dma16(wb + wo[k], wd + k * (NTH * 4));
     };
 
-    __syncthreads();                                         // tables written (no DMA in flight yet)
-    stage(0, 0);
+    stage(0, 0);                                             // (first: the parameter tables are filled while it flies)
+    fill_param_table<BN, false>(a, Pm, n0, tid, NTH);
+    if constexpr (SN) {
+        for (int c = tid; c < a.Cin; c += NTH) {
+            Sp[2 * c] = a.sn_a[c];
+            Sp[2 * c + 1] = a.sn_ib[c];
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     for (int cb = 0; cb < ncb; cb++) {
         const int buf = cb & 1;
@@ -924,18 +923,19 @@ bool wino_selected(const ConvGemmArgs &a) {
 
 static int wino_rt();
 const char *wino_kernel_name(const ConvGemmArgs &a) {      // as rocprofv3 prints it
-    if (wino_unit_selected(a)) return a.shift_step == 1 ? "wino_ps_kernel<1,3,true>" : a.shift_step == 3 ? "wino_ps_kernel<3,3,true>" : "wino_ps_kernel<9,3,true>";
+    if (wino_unit_selected(a)) return a.shift_step == 1 ? "wino_ps_kernel<1,3,true,4,16>" : a.shift_step == 3 ? "wino_ps_kernel<3,3,true,4,16>" : "wino_ps_kernel<9,3,true,4,16>";
     if (wino_tconv_selected(a)) {
         const bool big = a.N % 128 == 0;
         if (a.sn_a) return big ? "wino_tconv_kernel<true,2,2>" : "wino_tconv_kernel<true,1,3>";
         return big ? "wino_tconv_kernel<false,2,2>" : "wino_tconv_kernel<false,1,3>";
     }
-    static char names[2][3][4][44];
-    const int di = a.shift_step == 1 ? 0 : a.shift_step == 3 ? 1 : 2, sn = a.sn_a ? 1 : 0, mode = sn && wino_rt() == 3 ? 1 : wino_rt();
-    const int mi = mode == 1 ? 0 : mode == 2 ? 1 : mode == 4 ? 2 : 3;
+    static char names[2][3][5][44];
+    const int di = a.shift_step == 1 ? 0 : a.shift_step == 3 ? 1 : 2, sn = a.sn_a ? 1 : 0, mode = sn && (wino_rt() == 3 || wino_rt() == 5) ? 1 : wino_rt();
+    const int mi = mode == 1 ? 0 : mode == 2 ? 1 : mode == 4 ? 2 : mode == 3 ? 3 : 4;
     char *n = names[sn][di][mi];
     if (!n[0]) {
-        if (mode == 3) snprintf(n, 44, "wino_ps_kernel<%d,2,false>", a.shift_step);
+        if (mode == 3) snprintf(n, 44, "wino_ps_kernel<%d,2,false,4,16>", a.shift_step);
+        else if (mode == 5) snprintf(n, 44, "wino_ps_kernel<%d,2,false,2,8>", a.shift_step);
         else snprintf(n, 44, "wino_conv7_kernel<%d,%s,%d,%d>", a.shift_step, sn ? "true" : "false", mode == 2 ? 2 : 1, mode == 1 ? 2 : 1);
     }
     return n;
@@ -944,14 +944,16 @@ const char *wino_kernel_name(const ConvGemmArgs &a) {      // as rocprofv3 print
 // HIPVOC_WINO_RT: shape of a workgroup of wino_conv7_kernel<D, SN, RT, RH> (RT row tiles per wave, RH row groups of waves).
 //   1:           RT 1, RH 2 -- 64 rows, 8 waves, two per SIMD
 //   2:           RT 2, RH 1 -- 64 rows, 4 waves, one per SIMD (256 accumulator registers)
-//   4 (default): RT 1, RH 1 -- 32 rows, 4 waves; two INDEPENDENT workgroups per CU, so one's barrier and block prologue
+//   4:           RT 1, RH 1 -- 32 rows, 4 waves; two INDEPENDENT workgroups per CU, so one's barrier and block prologue
 //                              overlap the other's MFMAs
-//   3:           wino_ps_kernel<D, 2, false>: 64 rows, 8 waves, the eight points split over two waves (no SN form: such
-//                              layers run in shape 1)
-static int wino_rt() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("HIPVOC_WINO_RT"); const int x = e ? atoi(e) : WN_MODE_DEFAULT; v = x == 2 ? 2 : x == 4 ? 4 : x == 3 ? 3 : 1; }
-    return v;
+//   3:           wino_ps_kernel<D, 2, false, 4, 16>: 64 rows, 8 waves, the eight points split over two waves (no SN form:
+//                              such layers run in shape 1)
+//   5 (default): wino_ps_kernel<D, 2, false, 2, 8>: the same in 4-wave workgroups of 64 tiles and 8-channel blocks, two
+//                              independent workgroups per CU
+static int wino_rt() {                                   // (read at every launch: a handful of getenv calls per pass; lets one process compare shapes)
+    const char *e = getenv("HIPVOC_WINO_RT");
+    const int x = e ? atoi(e) : WN_MODE_DEFAULT;
+    return x == 2 ? 2 : x == 4 ? 4 : x == 3 ? 3 : x == 5 ? 5 : x == 1 ? 1 : WN_MODE_DEFAULT;
 }
 
 template <int D, bool SN, int RT, int RH>
@@ -980,11 +982,12 @@ static hipError_t wino_launch_one(const ConvGemmArgs &a, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <int D, int RT, bool FUSE>
+template <int D, int RT, bool FUSE, int NTG, int BK>
 static hipError_t wino_ps_launch_one(const ConvGemmArgs &a, hipStream_t s) {
-    using GEO = PsGeom<D, RT>;
+    using GEO = PsGeom<D, RT, NTG, BK>;
+    if (a.Cin % BK) return hipErrorInvalidValue;
     const int n_pairs = (a.M + 2 * D - 1) / (2 * D) * D;     // tiles of a unit, as wino_launch_one
-    const int wg_per_unit = (n_pairs + WN_NT - 1) / WN_NT;
+    const int wg_per_unit = (n_pairs + GEO::NT - 1) / GEO::NT;
     const int n_tiles = a.N / GEO::BN;
     const long grid = (long)wg_per_unit * a.units * n_tiles;
     if (grid > 0x7fffffffL) return hipErrorInvalidValue;
@@ -995,11 +998,11 @@ static hipError_t wino_ps_launch_one(const ConvGemmArgs &a, hipStream_t s) {
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 64 && !done[dev]) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(wino_ps_kernel<D, RT, FUSE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(wino_ps_kernel<D, RT, FUSE, NTG, BK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         done[dev] = true;
     }
-    hipLaunchKernelGGL((wino_ps_kernel<D, RT, FUSE>), dim3((unsigned)grid), dim3(GEO::NTH), lds, s, a, wg_per_unit, n_tiles);
+    hipLaunchKernelGGL((wino_ps_kernel<D, RT, FUSE, NTG, BK>), dim3((unsigned)grid), dim3(GEO::NTH), lds, s, a, wg_per_unit, n_tiles);
     return hipGetLastError();
 }
 
@@ -1037,7 +1040,7 @@ hipError_t launch_wino_conv7(const ConvGemmArgs &a, hipStream_t s) {
     if (!a.zeros) return hipErrorInvalidValue;
     if (wino_unit_selected(a)) {
         if ((a.x_cs & 3) || (a.x_us & 3) || ((uintptr_t)a.x & 15) || ((uintptr_t)a.ww & 15) || ((uintptr_t)a.w2 & 15) || a.Lin < 1) return hipErrorInvalidValue;
-        return a.shift_step == 1 ? wino_ps_launch_one<1, 3, true>(a, s) : a.shift_step == 3 ? wino_ps_launch_one<3, 3, true>(a, s) : wino_ps_launch_one<9, 3, true>(a, s);
+        return a.shift_step == 1 ? wino_ps_launch_one<1, 3, true, 4, 16>(a, s) : a.shift_step == 3 ? wino_ps_launch_one<3, 3, true, 4, 16>(a, s) : wino_ps_launch_one<9, 3, true, 4, 16>(a, s);
     }
     if (wino_tconv_selected(a)) {
         if ((a.x_cs & 3) || (a.x_us & 3) || ((uintptr_t)a.x & 15) || ((uintptr_t)a.ww & 15) || (a.NP & 3) || (a.sn_a && !a.sn_ib) || a.Cin > 4096)
@@ -1051,8 +1054,9 @@ hipError_t launch_wino_conv7(const ConvGemmArgs &a, hipStream_t s) {
         (a.sn_a && !a.sn_ib) || a.Cin > 4096)
         return hipErrorInvalidValue;
     const bool sn = a.sn_a != nullptr;
-    const int mode = sn && wino_rt() == 3 ? 1 : wino_rt();
-    if (mode == 3) return a.shift_step == 1 ? wino_ps_launch_one<1, 2, false>(a, s) : a.shift_step == 3 ? wino_ps_launch_one<3, 2, false>(a, s) : wino_ps_launch_one<9, 2, false>(a, s);
+    const int mode = sn && (wino_rt() == 3 || wino_rt() == 5) ? 1 : wino_rt();
+    if (mode == 3) return a.shift_step == 1 ? wino_ps_launch_one<1, 2, false, 4, 16>(a, s) : a.shift_step == 3 ? wino_ps_launch_one<3, 2, false, 4, 16>(a, s) : wino_ps_launch_one<9, 2, false, 4, 16>(a, s);
+    if (mode == 5) return a.shift_step == 1 ? wino_ps_launch_one<1, 2, false, 2, 8>(a, s) : a.shift_step == 3 ? wino_ps_launch_one<3, 2, false, 2, 8>(a, s) : wino_ps_launch_one<9, 2, false, 2, 8>(a, s);
 #define WN_GO2(D_, SN_) (mode == 1 ? wino_launch_one<D_, SN_, 1, 2>(a, s) : mode == 2 ? wino_launch_one<D_, SN_, 2, 1>(a, s) : wino_launch_one<D_, SN_, 1, 1>(a, s))
 #define WN_GO(D_) (sn ? WN_GO2(D_, true) : WN_GO2(D_, false))
     switch (a.shift_step) {

@@ -356,3 +356,39 @@ def test_winograd_conv7_against_the_direct_kernels(pkg, synth, vo, monkeypatch):
         v.close()
     assert float(np.abs(out["0"] - out["1"]).max()) <= 1e-4
     assert snr_db(out["0"], out["1"]) >= 75.0
+
+
+@pytest.mark.gpu
+def test_winograd_workgroup_shapes_agree(pkg, synth, monkeypatch):
+    """The k = 7 convs have five workgroup shapes (HIPVOC_WINO_RT, kernels_wino.hip: 8 waves x 8 points, 4 waves x 2 row tiles,
+    4 waves x 32 rows, and the two point-split forms) and block 3's residual units two forms (the fused Winograd unit and, with
+    HIPVOC_WINO_UNIT=0, the fused direct kernel).  Same arithmetic per output up to the order of the output transform's sums:
+    every shape must give the default's waveform to within fp32 round-off, and must really run the kernel it names."""
+    cfg = synth.FULL
+    voc_for(pkg, synth, "FULL", 0, 64)                         # makes the checkpoint file
+    path = os.path.join(tempfile.gettempdir(), "hipvoc_test_FULL_0.safetensors")
+    codes = synth.make_codes(125, 1000, cfg)
+
+    def run(env):
+        for k, val in env.items():
+            monkeypatch.setenv(k, val)
+        v = pkg.HipVocoder.load(path, device=0, unit_frames=64)
+        v.set_profile(True)
+        out = v.synthesize(codes)
+        names = sorted({k.split("|")[1] for k in v.last_profile()})
+        v.close()
+        for k in env:
+            monkeypatch.delenv(k)
+        return out, names
+
+    ref, names = run({})
+    assert any(n.startswith("wino_ps_kernel<1,3,true") for n in names), names         # block 3: fused Winograd units
+    want = {"1": "wino_conv7_kernel<1,false,1,2>", "2": "wino_conv7_kernel<1,false,2,1>", "4": "wino_conv7_kernel<1,false,1,1>",
+            "3": "wino_ps_kernel<1,2,false,4,16>", "5": "wino_ps_kernel<1,2,false,2,8>"}
+    for mode, kname in want.items():
+        out, names = run({"HIPVOC_WINO_RT": mode})
+        assert kname in names, (mode, names)
+        assert float(np.abs(out - ref).max()) <= 2e-5 and snr_db(ref, out) >= 90.0, (mode, float(np.abs(out - ref).max()), snr_db(ref, out))
+    out, names = run({"HIPVOC_WINO_UNIT": "0"})
+    assert "conv_gemm_kernel<3,true,4,false>" in names and not any(n.startswith("wino_ps_kernel<1,3,true") for n in names), names
+    assert float(np.abs(out - ref).max()) <= 5e-5 and snr_db(ref, out) >= 85.0, (float(np.abs(out - ref).max()), snr_db(ref, out))
