@@ -381,6 +381,7 @@ const char *conv_gemm_kernel_name(const ConvGemmArgs &a) {
     if (wino_selected(a)) return wino_kernel_name(a);
     if (gemm1_selected(a)) return gemm1_kernel_name(a);
     if (convs_selected(a)) return convs_kernel_name(a);
+    if (gemmd_selected(a)) return gemmd_kernel_name(a);
     static char names[3][2][8][48];
     int tn = conv_gemm_launch_tn(a);
     int fuse = a.w2 ? 1 : 0, nw = conv_gemm_waves(a);
@@ -423,6 +424,7 @@ hipError_t launch_conv_gemm(const ConvGemmArgs &a_in, hipStream_t s) {
     if (wino_selected(a_in)) return launch_wino_conv7(a_in, s);
     if (gemm1_selected(a_in)) return launch_gemm1(a_in, s);
     if (convs_selected(a_in)) return launch_convs(a_in, s);
+    if (gemmd_selected(a_in)) return launch_gemmd(a_in, s);
     ConvGemmArgs a = a_in;
     {   // timing-only ablation switch (HIPVOC_DBG bit0: stage the activation tile only once; bit1: the weight tile only once; bit2: no barriers; bit3: main loop only).  Results are
         // WRONG with it set; never set in production.

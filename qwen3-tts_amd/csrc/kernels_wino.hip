@@ -105,7 +105,12 @@ __device__ __forceinline__ void wn_dma16(const float *g, float *lds) {
 // stays on the scalar unit (a 64-bit VALU add per piece is matrix-pipe time on this chip, see wino_ps_kernel's header)
 __device__ __forceinline__ void wn_dma16_s(const float *sbase, unsigned voff_bytes, float *lds) {
     const unsigned l = (unsigned)(size_t)(wn_lptr_t)lds;
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(l), "v"(voff_bytes), "s"(sbase) : "memory");
+    // (the base is wave-uniform by construction; readfirstlane makes the compiler keep it in SGPRs whatever unit computed it)
+    const unsigned long long b = (unsigned long long)sbase;
+    // (readfirstlane returns int: both halves go through unsigned, or the low half's top bit would sign-extend into the high one)
+    const unsigned b_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32)), b_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);
+    const unsigned long long bs = ((unsigned long long)b_hi << 32) | (unsigned long long)b_lo;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(l), "v"(voff_bytes), "s"(bs) : "memory");
 }
 
 // SN: the conv has a SnakeBeta prologue (a.sn_a / a.sn_ib), applied to the inputs as they are read from LDS
@@ -1066,6 +1071,140 @@ hipError_t launch_wino_conv7(const ConvGemmArgs &a, hipStream_t s) {
     }
 #undef WN_GO
 #undef WN_GO2
+}
+
+// -------------------------------------------------------------------------------------------------------------------------
+// gemm_dma_kernel<TN>: the plain 1-tap GEMMs of large launches (1x1 convs of the residual units, pointwise convs) with BOTH
+// operands staged by LDS-DMA.  Same tile (32 TN rows x 256 positions, 8 waves, wave = all rows x 32 positions), the same MFMA
+// chain per output element (16-channel blocks, k pairs ascending, k = 2 kk + h) and the same epilogue as conv_gemm_kernel, so the
+// results are bit-identical to it and to gemm1_kernel; what goes away is the register-staged prefetch and its commit pass --
+// VALU instructions that take matrix-pipe cycles on this chip (see wino_ps_kernel's header).  Needs an input that is already
+// activated (no sn_*), Cin % 16 == 0 and M == Lin; positions past the row's end are fetched from a clamped address and only
+// ever reach outputs that are not stored.
+template <int TN>
+__global__ __launch_bounds__(512, 2) void gemm_dma_kernel(ConvGemmArgs a, int tiles_per_unit, int n_tiles) {
+    constexpr int NTH = 512, BM = 256, BN = 32 * TN, GK = 16;
+    constexpr int XBUF = GK * BM, WBUF = GK * BN, WF4 = GK * BN / 4;
+    static_assert(WF4 <= NTH, "one weight piece per thread");
+    extern __shared__ __attribute__((aligned(16))) float smem_all[];
+    float *Pm = smem_all;                                   // [4][BN] per-row parameters
+    float *Xs = smem_all + 4 * BN;                          // [2][16][256]
+    float *Ws = Xs + 2 * XBUF;                              // [2][16][BN]
+
+    int nwg = gridDim.x, orig = blockIdx.x;                 // XCD-aware remap, as conv_gemm_kernel
+    int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+    int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    const int nt = id % n_tiles;
+    const int pt = id / n_tiles;
+    const int unit = pt / tiles_per_unit;
+    const int m0 = (pt - unit * tiles_per_unit) * BM;
+    const int n0 = nt * BN;
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const float *xu = a.x + (long)unit * a.x_us;
+    const int ncb = a.Cin / GK;
+
+    f32x16 acc[TN];
+#pragma unroll
+    for (int i = 0; i < TN; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][r] = 0.0f;
+
+    // pieces (16 B per lane): X image [16][256] = 1024 float4 -> two per thread; W image [16][BN] -> at most one
+    const int xlim = ((a.Lin + 3) & ~3) - 4;
+    unsigned xvo[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int i = tid + NTH * j, row = i >> 6, c4 = i & 63;
+        int pos = m0 + 4 * c4;
+        pos = pos > xlim ? xlim : pos;
+        xvo[j] = ((unsigned)row * (unsigned)a.x_cs + (unsigned)pos) * 4u;
+    }
+    const int wrow = tid / (BN / 4), wc4 = tid - wrow * (BN / 4);
+    const unsigned wvo = ((unsigned)(wrow < GK ? wrow : 0) * (unsigned)a.NP + (unsigned)wc4 * 4u) * 4u;
+    auto stage = [&](int cb, int buf) {
+        const float *xb = xu + (long)cb * GK * a.x_cs;
+        float *xd = Xs + buf * XBUF + wave * 256;
+        wn_dma16_s(xb, xvo[0], xd);
+        wn_dma16_s(xb, xvo[1], xd + NTH * 4);
+        const float *wb = a.w + ((long)cb * GK) * a.NP + n0;
+        if (WF4 >= NTH || tid < WF4) wn_dma16_s(wb, wvo, Ws + buf * WBUF + wave * 256);
+    };
+
+    stage(0, 0);                                             // (first: the parameter table is filled while it flies)
+    fill_param_table<BN, false>(a, Pm, n0, tid, NTH);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int cb = 0; cb < ncb; cb++) {
+        const int buf = cb & 1;
+        if (cb + 1 < ncb) stage(cb + 1, buf ^ 1);
+        {
+            const float *ws = Ws + buf * WBUF + l31;
+            const float *xs = Xs + buf * XBUF + wave * 32 + l31;
+#pragma unroll
+            for (int kk = 0; kk < GK / 2; kk++) {
+                const int k = 2 * kk + h;
+                float av[TN];
+#pragma unroll
+                for (int i = 0; i < TN; i++) av[i] = ws[k * BN + i * 32];
+                const float bv = xs[k * BM];
+#pragma unroll
+                for (int i = 0; i < TN; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv, acc[i], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+
+    float *yu = a.y + (long)unit * a.y_us;
+    const float *ru0 = launder_after(a.res, acc[TN - 1][15]);
+    const float *ru = ru0 ? ru0 + (long)unit * a.y_us : nullptr;
+    float *y2u0 = launder_after(a.y2, acc[TN - 1][15]);
+    float *y2u = y2u0 ? y2u0 + (long)unit * a.y_us : nullptr;
+    const int m = m0 + wave * 32 + l31;
+#pragma unroll
+    for (int i = 0; i < TN; i++) conv_epilogue_tile<BN, false>(a, acc[i], Pm, n0, i * 32 + 4 * h, m, yu, ru, y2u);
+}
+
+// HIPVOC_GEMMD=0 turns it off (conv_gemm_kernel runs instead: same bits)
+bool gemmd_selected(const ConvGemmArgs &a) {
+    const char *e = getenv("HIPVOC_GEMMD");
+    const bool off = e && atoi(e) == 0;
+    const bool sel = !a.wb && !a.w2 && a.w && a.ntaps == 1 && a.S == 1 && a.shift0 == 0 && !a.sn_a && !a.xb && !a.yb && !a.in_elu && a.s2d <= 1 &&
+           (a.act == ACT_NONE || a.act == ACT_GELU || a.act == ACT_CLAMP1) && a.Cin >= 16 && a.Cin % 16 == 0 && a.M == a.Lin && a.units >= 1 &&
+           a.TN >= 1 && a.TN <= 4 && a.NP % (32 * a.TN) == 0 && a.NP >= a.N && a.y && (!a.y2 || (a.psn_a && a.psn_ib));
+    if (sel && getenv("HIPVOC_GEMMD_TRACE"))
+        fprintf(stderr, "GEMMD cand: Cin %d N %d NP %d TN %d tn %d M %d Lin %d units %d x_cs %ld x_us %ld y_cs %ld y_us %ld act %d res %d rscale %d y2 %d psn %d bias %d S %d pm %d\n",
+                a.Cin, a.N, a.NP, a.TN, detail::conv_gemm_launch_tn(a), a.M, a.Lin, a.units, (long)a.x_cs, (long)a.x_us, (long)a.y_cs, (long)a.y_us, a.act,
+                a.res != nullptr, a.rscale != nullptr, a.y2 != nullptr, a.psn_a != nullptr, a.bias != nullptr, a.S, a.pm);
+    return sel && !off;
+}
+
+const char *gemmd_kernel_name(const ConvGemmArgs &a) {
+    static const char *n[5] = {"", "gemm_dma_kernel<1>", "gemm_dma_kernel<2>", "gemm_dma_kernel<3>", "gemm_dma_kernel<4>"};
+    const int tn = detail::conv_gemm_launch_tn(a);
+    return n[tn >= 1 && tn <= 4 ? tn : 4];
+}
+
+template <int TN>
+static hipError_t gemmd_launch_one(const ConvGemmArgs &a, hipStream_t s) {
+    const int tiles_per_unit = (a.M + 255) / 256, n_tiles = a.NP / (32 * TN);
+    const long grid = (long)tiles_per_unit * a.units * n_tiles;
+    if (grid > 0x7fffffffL) return hipErrorInvalidValue;
+    const size_t lds = sizeof(float) * (4 * 32 * TN + 2 * 16 * 256 + 2 * 16 * 32 * TN);
+    hipLaunchKernelGGL((gemm_dma_kernel<TN>), dim3((unsigned)grid), dim3(512), lds, s, a, tiles_per_unit, n_tiles);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemmd(const ConvGemmArgs &a, hipStream_t s) {
+    if (!gemmd_selected(a)) return hipErrorInvalidValue;
+    if (a.M <= 0) return hipSuccess;
+    if ((a.x_cs & 3) || (a.x_us & 3) || ((uintptr_t)a.x & 15) || ((uintptr_t)a.w & 15) || (a.NP & 3) || a.Lin < 1) return hipErrorInvalidValue;
+    switch (detail::conv_gemm_launch_tn(a)) {
+        case 1: return gemmd_launch_one<1>(a, s);
+        case 2: return gemmd_launch_one<2>(a, s);
+        case 3: return gemmd_launch_one<3>(a, s);
+        default: return gemmd_launch_one<4>(a, s);
+    }
 }
 
 }  // namespace hipvoc

@@ -392,3 +392,30 @@ def test_winograd_workgroup_shapes_agree(pkg, synth, monkeypatch):
     out, names = run({"HIPVOC_WINO_UNIT": "0"})
     assert "conv_gemm_kernel<3,true,4,false>" in names and not any(n.startswith("wino_ps_kernel<1,3,true") for n in names), names
     assert float(np.abs(out - ref).max()) <= 5e-5 and snr_db(ref, out) >= 85.0, (float(np.abs(out - ref).max()), snr_db(ref, out))
+
+
+@pytest.mark.gpu
+def test_gemm_dma_bitwise(pkg, synth, monkeypatch):
+    """gemm_dma_kernel (the large 1-tap GEMMs with both operands staged by LDS-DMA) runs the same MFMA chain per output as
+    conv_gemm_kernel and gemm1_kernel: with it off (HIPVOC_GEMMD=0) the waveform is the same bit for bit, at a large launch
+    (64 units: it is selected for the 1x1 convs) and at a small one (2 units: gemm1_kernel takes those layers either way)."""
+    cfg = synth.FULL
+    voc_for(pkg, synth, "FULL", 0, 64)
+    path = os.path.join(tempfile.gettempdir(), "hipvoc_test_FULL_0.safetensors")
+    codes = [synth.make_codes(125, 3000 + i, cfg) for i in range(6)]
+    outs = {}
+    for on in ("1", "0"):
+        monkeypatch.setenv("HIPVOC_GEMMD", on)
+        v = pkg.HipVocoder.load(path, device=0, unit_frames=64)
+        v.set_profile(True)
+        big = v.synthesize_batch(codes) if hasattr(v, "synthesize_batch") else [v.synthesize(c) for c in codes]
+        names = {k.split("|")[1] for k in v.last_profile()}
+        small = v.synthesize(codes[0])
+        v.close()
+        outs[on] = (big, small, names)
+    assert any(n.startswith("gemm_dma_kernel") for n in outs["1"][2]), outs["1"][2]
+    assert not any(n.startswith("gemm_dma_kernel") for n in outs["0"][2]), outs["0"][2]
+    for x, y in zip(outs["1"][0], outs["0"][0]):
+        assert np.array_equal(np.asarray(x).view(np.uint32), np.asarray(y).view(np.uint32))
+    assert np.array_equal(outs["1"][1].view(np.uint32), outs["0"][1].view(np.uint32))
+    assert np.array_equal(np.asarray(outs["1"][0][0]).view(np.uint32), outs["1"][1].view(np.uint32))      # batch == single
