@@ -88,6 +88,7 @@ def parse_args(argv=None):
     ap.add_argument("--frames", type=int, default=LONGFORM_FRAMES, help="frames of the long-form stream")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-host", action="store_true", help="skip the host-to-host leg")
+    ap.add_argument("--no-latency", action="store_true", help="skip the single-utterance latency leg (profiling runs: keeps small launches out of the per-kernel averages)")
     ap.add_argument("--dtype", choices=["f32", "bf16", "bf16x3"], default=None,
                     help="f32 (the reference's precision and the headline number; default of batch256 / longform), the bf16 "
                          "conv-GEMM mode (default of batch4096, BASELINE configs[4]; separately stated tolerance) or the "
@@ -312,7 +313,7 @@ def main(argv=None):
 
     # ---------------------------------------------------------------- single-utterance latency (configs[1]), PCIe included
     lat_ms = None
-    if rank == 0 and not stub:
+    if rank == 0 and not stub and not args.no_latency:
         c1 = synth.make_codes(FRAMES_PER_UTT, 1000, cfg)
         voc.synthesize(c1)
         ts = []
