@@ -67,6 +67,20 @@ static constexpr int WN_PTS = 8;
 #ifndef PS_ABL
 #define PS_ABL 0   // timing-only ablation bits (results are wrong with any set)
 #endif
+#ifndef WN_UNIT_WG_DEFAULT
+#define WN_UNIT_WG_DEFAULT 8
+#endif
+// LDS operand reads: volatile keeps hipcc from merging neighbouring reads into ds_read2 forms, whose 8-bit offsets force a
+// VALU address add per step (matrix-pipe time); single ds_read_b32 take the whole step offset as a 16-bit immediate
+#ifndef WN_LDS_VOLATILE
+#define WN_LDS_VOLATILE 1
+#endif
+#if WN_LDS_VOLATILE
+typedef const volatile __attribute__((address_space(3))) float *wn_vlds_t;
+#define WN_LDS(p_) (*(wn_vlds_t)(p_))
+#else
+#define WN_LDS(p_) (*(p_))
+#endif
 #ifndef WN_DG
 #define WN_DG 2
 #endif
@@ -391,10 +405,17 @@ struct PsGeom {
     static constexpr int WP = WF4 / NTH;
     static constexpr int WBUF = WN_PTS * BK * BN;
     static constexpr int EX = 2 * NTG * RT * 16 * 64;                     // floats of the partial-sum exchange: [wave][RT * 16][lane]
+    static constexpr int EXH = NTG * RT * 16 * 64;                        // ... of one direction of it (two-phase exchange)
     static constexpr int W2F = BN * BN;                                   // FUSE: the 1x1 conv's weights [k][BN]
     static constexpr int W2P = (W2F / 4 + NTH - 1) / NTH;
     static constexpr int STAGE = 2 * XBUF + 2 * WBUF;
-    static constexpr int WORK(bool fuse) { return STAGE > EX + (fuse ? W2F : 0) ? STAGE : EX + (fuse ? W2F : 0); }
+    // FUSE in 4-wave workgroups (NTG == 2): the two directions of the exchange go one after the other through the same LDS,
+    // so that exchange + W2 stay under 80 KB and two workgroups share a CU
+    static constexpr bool two_phase(bool fuse) { return fuse && NTG == 2; }
+    static constexpr int WORK(bool fuse) {
+        const int need = (two_phase(fuse) ? EXH : EX) + (fuse ? W2F : 0);
+        return STAGE > need ? STAGE : need;
+    }
     static_assert(WF4 % NTH == 0 && (NTG == 2 || NTG == 4) && BK % 2 == 0, "geometry");
 };
 
@@ -490,14 +511,14 @@ __global__ __launch_bounds__((PsGeom<D, RT, NTG, BK>::NTH), (NTG == 2 ? 2 : 1)) 
                 auto load_d = [&](int kk, int sl) {
                     const float *xk = xs + (2 * kk + h) * XW;
 #pragma unroll
-                    for (int i = (PG ? 1 : 0); i < (PG ? 7 : 8); i++) dv[sl][i] = (PS_ABL & 2) ? (float)(kk + i) : xk[i * D];     // (the +-2, +-1/2 points do not see d0, d7)
+                    for (int i = (PG ? 1 : 0); i < (PG ? 7 : 8); i++) dv[sl][i] = (PS_ABL & 2) ? (float)(kk + i) : WN_LDS(xk + i * D);     // (the +-2, +-1/2 points do not see d0, d7)
                 };
                 auto load_a = [&](int kk, int sl) {
                     const float *wk = ws + (2 * kk + h) * BN;
 #pragma unroll
                     for (int q = 0; q < 4; q++)
 #pragma unroll
-                        for (int i = 0; i < RT; i++) av[sl][q][i] = (PS_ABL & 4) ? (float)(q + i + kk) : wk[q * (BK * BN) + 32 * i];
+                        for (int i = 0; i < RT; i++) av[sl][q][i] = (PS_ABL & 4) ? (float)(q + i + kk) : WN_LDS(wk + q * (BK * BN) + 32 * i);
                 };
                 auto transform = [&](int ds, int vs) {      // 12 VALU instructions either way
                     const float *d = dv[ds];
@@ -555,7 +576,8 @@ __global__ __launch_bounds__((PsGeom<D, RT, NTG, BK>::NTH), (NTG == 2 ? 2 : 1)) 
 
     // ---- the staging buffers are idle (the loop ended with a barrier): partial output transforms, exchange, finish
     float *Ex = Xs;                                          // [8 waves][RT * 16][64 lanes]
-    float *W2s = Xs + GEO::EX;                               // FUSE: [BN k rows][BN]
+    constexpr bool TWO = GEO::two_phase(FUSE);
+    float *W2s = Xs + (TWO ? GEO::EXH : GEO::EX);            // FUSE: [BN k rows][BN]
     if constexpr (FUSE) {
 #pragma unroll
         for (int j = 0; j < GEO::W2P; j++) {
@@ -563,7 +585,7 @@ __global__ __launch_bounds__((PsGeom<D, RT, NTG, BK>::NTH), (NTG == 2 ? 2 : 1)) 
             if (NTH * (j + 1) <= GEO::W2F / 4 || i < GEO::W2F / 4) wn_dma16(a.w2 + 4 * (long)i, W2s + wave * 256 + j * (NTH * 4));
         }
     }
-    float yv[RT][16];
+    float yv[RT][16], snd[TWO ? RT : 1][16];
     {
         float *exw = Ex + (wave * RT * 16) * 64 + lane;
         if (pg == 0) {                                       // M0 M1 M2 M7 here: keep M0 + M1 + M2, send M1 - M2 + M7
@@ -573,7 +595,8 @@ __global__ __launch_bounds__((PsGeom<D, RT, NTG, BK>::NTH), (NTG == 2 ? 2 : 1)) 
                 for (int r = 0; r < 16; r++) {
                     const float m0 = acc[0][i][r], m1 = acc[1][i][r], m2 = acc[2][i][r], m3 = acc[3][i][r];
                     yv[i][r] = (m1 + m2) + m0;
-                    exw[(i * 16 + r) * 64] = (m1 - m2) + m3;
+                    if constexpr (TWO) snd[i][r] = (m1 - m2) + m3;
+                    else exw[(i * 16 + r) * 64] = (m1 - m2) + m3;
                 }
         } else {                                             // M3 M4 M5 M6 here: keep 2 (M3 - M4) + (M5 - M6) / 2, send their sum
 #pragma unroll
@@ -582,11 +605,12 @@ __global__ __launch_bounds__((PsGeom<D, RT, NTG, BK>::NTH), (NTG == 2 ? 2 : 1)) 
                 for (int r = 0; r < 16; r++) {
                     const float m0 = acc[0][i][r], m1 = acc[1][i][r], m2 = acc[2][i][r], m3 = acc[3][i][r];
                     yv[i][r] = fmaf(2.0f, m0 - m1, 0.5f * (m2 - m3));
-                    exw[(i * 16 + r) * 64] = (m0 + m1) + (m2 + m3);
+                    if constexpr (TWO) snd[i][r] = (m0 + m1) + (m2 + m3);
+                    else exw[(i * 16 + r) * 64] = (m0 + m1) + (m2 + m3);
                 }
         }
     }
-    const int pos = p + pg * D;                              // this wave finishes y[p] (waves 0-3) or y[p + D] (waves 4-7)
+    const int pos = p + pg * D;                              // this wave finishes y[p] (point group 0) or y[p + D] (group 1)
     const bool ok = pos < a.M;
     // FUSE: the residual x[row][pos] of all BN rows is requested BEFORE the exchange barrier (the accumulators are dead, the
     // registers free) and used after the second product.  vmcnt retires in order and the W2 pieces were issued first, so the
@@ -599,11 +623,40 @@ __global__ __launch_bounds__((PsGeom<D, RT, NTG, BK>::NTH), (NTG == 2 ? 2 : 1)) 
 #pragma unroll
             for (int r = 0; r < 16; r++) resv[i][r] = rup[(long)(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * a.y_cs];
         static_assert(RT * 16 <= 63, "vmcnt range");
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(RT * 16) : "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
-    {
+    if constexpr (TWO) {
+        // one direction at a time through [tile group][RT * 16][lane]: group 1 -> group 0, then group 0 -> group 1
+        float *exh = Ex + (tw * RT * 16) * 64 + lane;
+        if (pg == 1) {
+#pragma unroll
+            for (int i = 0; i < RT; i++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) exh[(i * 16 + r) * 64] = snd[i][r];
+        }
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(RT * 16) : "memory");     // (also: W2 has landed)
+        if (pg == 0) {
+#pragma unroll
+            for (int i = 0; i < RT; i++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) yv[i][r] += exh[(i * 16 + r) * 64];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                              // group 0 has read
+        if (pg == 0) {
+#pragma unroll
+            for (int i = 0; i < RT; i++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) exh[(i * 16 + r) * 64] = snd[i][r];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (pg == 1) {
+#pragma unroll
+            for (int i = 0; i < RT; i++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) yv[i][r] += exh[(i * 16 + r) * 64];
+        }
+    } else {
+        if constexpr (FUSE) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(RT * 16) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         const float *exr = Ex + ((wave ^ NTG) * RT * 16) * 64 + lane;
 #pragma unroll
         for (int i = 0; i < RT; i++)
@@ -637,24 +690,28 @@ __global__ __launch_bounds__((PsGeom<D, RT, NTG, BK>::NTH), (NTG == 2 ? 2 : 1)) 
                 yv[i][r + 1] = hv.y;
             }
         float *y2u = a.y2 ? a.y2 + (long)unit * a.y_us : nullptr;
+        // the 1x1 conv: all RT output tiles at once -- RT independent accumulator chains, each B value feeds RT MFMAs
+        f32x16 acc2[RT];
+#pragma unroll
+        for (int o = 0; o < RT; o++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc2[o][r] = 0.0f;
+        const float *ws2 = W2s + l31 + 4 * h * BN;
+#pragma unroll
+        for (int i = 0; i < RT; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int k = i * 32 + (r & 3) + 8 * (r >> 2);                    // this lane half's k is k + 4h
+#pragma unroll
+                for (int o = 0; o < RT; o++) acc2[o] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws2[k * BN + o * 32], yv[i][r], acc2[o], 0, 0, 0);
+                if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);              // (bounds how many LDS reads are hoisted)
+            }
 #pragma unroll
         for (int o = 0; o < RT; o++) {
-            f32x16 acc2;
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc2[r] = 0.0f;
-            const float *ws2 = W2s + o * 32 + l31 + 4 * h * BN;
-#pragma unroll
-            for (int i = 0; i < RT; i++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int k = i * 32 + (r & 3) + 8 * (r >> 2);                // this lane half's k is k + 4h
-                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ws2[k * BN], yv[i][r], acc2, 0, 0, 0);
-                    if ((r & 7) == 7) __builtin_amdgcn_sched_barrier(0);
-                }
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 const int n = o * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                f32x2 v = mk2(acc2[r] + Pm[3 * BN + n] + resv[o][r], acc2[r + 1] + Pm[3 * BN + n + 1] + resv[o][r + 1]);
+                f32x2 v = mk2(acc2[o][r] + Pm[3 * BN + n] + resv[o][r], acc2[o][r + 1] + Pm[3 * BN + n + 1] + resv[o][r + 1]);
                 float *yr = yu + (long)n * a.y_cs + pos;
                 if (a.psn_a) {
                     const f32x2 sv = snake_beta2(v, mk2(Pm[4 * BN + n], Pm[4 * BN + n + 1]), mk2(Pm[5 * BN + n], Pm[5 * BN + n + 1]));
@@ -794,7 +851,7 @@ __global__ __launch_bounds__((TconvGeom<RT, RW>::NTH), 1) void wino_tconv_kernel
             auto load_d = [&](int kk, int sl) {
                 const float *xk = xs + (2 * kk + h) * XW;
 #pragma unroll
-                for (int i = 0; i < 4; i++) dv[sl][i] = xk[i];
+                for (int i = 0; i < 4; i++) dv[sl][i] = WN_LDS(xk + i);
                 if constexpr (SN) sv[sl] = *reinterpret_cast<const float2 *>(sp + 4 * kk);
             };
             auto load_a = [&](int kk, int sl) {
@@ -802,7 +859,7 @@ __global__ __launch_bounds__((TconvGeom<RT, RW>::NTH), 1) void wino_tconv_kernel
 #pragma unroll
                 for (int q = 0; q < WT_PTS; q++)
 #pragma unroll
-                    for (int i = 0; i < RT; i++) av[sl][q][i] = wk[q * (WN_BK * BN) + 32 * i];
+                    for (int i = 0; i < RT; i++) av[sl][q][i] = WN_LDS(wk + q * (WN_BK * BN) + 32 * i);
             };
             auto transform = [&](int ds, int vs) {
                 float d[4];
@@ -927,8 +984,17 @@ bool wino_selected(const ConvGemmArgs &a) {
 }
 
 static int wino_rt();
+// HIPVOC_WINO_UNIT_WG: shape of the fused Winograd unit: 8 = 8 waves, 128 tiles, 16-channel blocks, one workgroup per CU;
+// 4 = 4 waves, 64 tiles, 8-channel blocks, two-phase exchange, two workgroups per CU
+static bool wino_unit_small() {
+    const char *e = getenv("HIPVOC_WINO_UNIT_WG");
+    return (e ? atoi(e) : WN_UNIT_WG_DEFAULT) == 4;
+}
 const char *wino_kernel_name(const ConvGemmArgs &a) {      // as rocprofv3 prints it
-    if (wino_unit_selected(a)) return a.shift_step == 1 ? "wino_ps_kernel<1,3,true,4,16>" : a.shift_step == 3 ? "wino_ps_kernel<3,3,true,4,16>" : "wino_ps_kernel<9,3,true,4,16>";
+    if (wino_unit_selected(a)) {
+        if (wino_unit_small()) return a.shift_step == 1 ? "wino_ps_kernel<1,3,true,2,8>" : a.shift_step == 3 ? "wino_ps_kernel<3,3,true,2,8>" : "wino_ps_kernel<9,3,true,2,8>";
+        return a.shift_step == 1 ? "wino_ps_kernel<1,3,true,4,16>" : a.shift_step == 3 ? "wino_ps_kernel<3,3,true,4,16>" : "wino_ps_kernel<9,3,true,4,16>";
+    }
     if (wino_tconv_selected(a)) {
         const bool big = a.N % 128 == 0;
         if (a.sn_a) return big ? "wino_tconv_kernel<true,2,2>" : "wino_tconv_kernel<true,1,3>";
@@ -1045,6 +1111,8 @@ hipError_t launch_wino_conv7(const ConvGemmArgs &a, hipStream_t s) {
     if (!a.zeros) return hipErrorInvalidValue;
     if (wino_unit_selected(a)) {
         if ((a.x_cs & 3) || (a.x_us & 3) || ((uintptr_t)a.x & 15) || ((uintptr_t)a.ww & 15) || ((uintptr_t)a.w2 & 15) || a.Lin < 1) return hipErrorInvalidValue;
+        if (wino_unit_small())
+            return a.shift_step == 1 ? wino_ps_launch_one<1, 3, true, 2, 8>(a, s) : a.shift_step == 3 ? wino_ps_launch_one<3, 3, true, 2, 8>(a, s) : wino_ps_launch_one<9, 3, true, 2, 8>(a, s);
         return a.shift_step == 1 ? wino_ps_launch_one<1, 3, true, 4, 16>(a, s) : a.shift_step == 3 ? wino_ps_launch_one<3, 3, true, 4, 16>(a, s) : wino_ps_launch_one<9, 3, true, 4, 16>(a, s);
     }
     if (wino_tconv_selected(a)) {
@@ -1146,7 +1214,7 @@ __global__ __launch_bounds__(512, 2) void gemm_dma_kernel(ConvGemmArgs a, int ti
                 const int k = 2 * kk + h;
                 float av[TN];
 #pragma unroll
-                for (int i = 0; i < TN; i++) av[i] = ws[k * BN + i * 32];
+                for (int i = 0; i < TN; i++) av[i] = ws[k * BN + i * 32];        // (merged ds_read2 forms are faster here than WN_LDS: measured)
                 const float bv = xs[k * BM];
 #pragma unroll
                 for (int i = 0; i < TN; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv, acc[i], 0, 0, 0);

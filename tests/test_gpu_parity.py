@@ -389,6 +389,9 @@ def test_winograd_workgroup_shapes_agree(pkg, synth, monkeypatch):
         out, names = run({"HIPVOC_WINO_RT": mode})
         assert kname in names, (mode, names)
         assert float(np.abs(out - ref).max()) <= 2e-5 and snr_db(ref, out) >= 90.0, (mode, float(np.abs(out - ref).max()), snr_db(ref, out))
+    out, names = run({"HIPVOC_WINO_UNIT_WG": "4"})             # the fused unit in 4-wave workgroups (two-phase exchange)
+    assert "wino_ps_kernel<1,3,true,2,8>" in names, names
+    assert float(np.abs(out - ref).max()) <= 2e-5 and snr_db(ref, out) >= 90.0, (float(np.abs(out - ref).max()), snr_db(ref, out))
     out, names = run({"HIPVOC_WINO_UNIT": "0"})
     assert "conv_gemm_kernel<3,true,4,false>" in names and not any(n.startswith("wino_ps_kernel<1,3,true") for n in names), names
     assert float(np.abs(out - ref).max()) <= 5e-5 and snr_db(ref, out) >= 85.0, (float(np.abs(out - ref).max()), snr_db(ref, out))
