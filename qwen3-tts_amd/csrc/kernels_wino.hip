@@ -973,6 +973,16 @@ static bool wino_unit_selected(const ConvGemmArgs &a) {
            a.s2d <= 1 && a.M == a.Lin && a.y && a.bias && a.bias2 && a.sn2_a && a.sn2_ib && (!a.y2 || a.psn_a) && (!a.psn_a || a.psn_ib);
 }
 
+// 128-row workgroups (8 waves) or 96-row ones (12 waves)?  96 when N allows nothing else, and on small launches (a single
+// utterance) where the 128-row grid would leave CUs idle: a third more workgroups, each a quarter shorter.  Per output element
+// both run the same chain of MFMAs and the same transforms: bit-identical (the batch == single tests cover it).
+static bool wino_tconv_rows128(const ConvGemmArgs &a) {
+    if (a.N % 128) return false;
+    if (a.N % 96) return true;
+    const long n_tl = (a.M + 2) / 3, wgs = ((n_tl + WN_NT - 1) / WN_NT) * (long)a.units * (a.N / 128);
+    return wgs > 192;
+}
+
 bool wino_selected(const ConvGemmArgs &a) {
     if (wino_unit_selected(a)) return true;
     if (!a.ww || a.wb || a.w2) return false;
@@ -996,7 +1006,7 @@ const char *wino_kernel_name(const ConvGemmArgs &a) {      // as rocprofv3 print
         return a.shift_step == 1 ? "wino_ps_kernel<1,3,true,4,16>" : a.shift_step == 3 ? "wino_ps_kernel<3,3,true,4,16>" : "wino_ps_kernel<9,3,true,4,16>";
     }
     if (wino_tconv_selected(a)) {
-        const bool big = a.N % 128 == 0;
+        const bool big = wino_tconv_rows128(a);
         if (a.sn_a) return big ? "wino_tconv_kernel<true,2,2>" : "wino_tconv_kernel<true,1,3>";
         return big ? "wino_tconv_kernel<false,2,2>" : "wino_tconv_kernel<false,1,3>";
     }
@@ -1119,7 +1129,7 @@ hipError_t launch_wino_conv7(const ConvGemmArgs &a, hipStream_t s) {
         if ((a.x_cs & 3) || (a.x_us & 3) || ((uintptr_t)a.x & 15) || ((uintptr_t)a.ww & 15) || (a.NP & 3) || (a.sn_a && !a.sn_ib) || a.Cin > 4096)
             return hipErrorInvalidValue;
         const bool sn = a.sn_a != nullptr;
-        if (a.N % 128 == 0) return sn ? wino_tconv_launch_one<true, 2, 2>(a, s) : wino_tconv_launch_one<false, 2, 2>(a, s);
+        if (wino_tconv_rows128(a)) return sn ? wino_tconv_launch_one<true, 2, 2>(a, s) : wino_tconv_launch_one<false, 2, 2>(a, s);
         return sn ? wino_tconv_launch_one<true, 1, 3>(a, s) : wino_tconv_launch_one<false, 1, 3>(a, s);
     }
     // host-side shape checks: what the kernel's 16-byte accesses assume
