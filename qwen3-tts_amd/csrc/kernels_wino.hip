@@ -943,7 +943,7 @@ __global__ __launch_bounds__((TconvGeom<RT, RW>::NTH), 1) void wino_tconv_kernel
             const int rbase = co * S - nw;                    // tile row of phase 0 of this channel (may be < 0)
             const int ph_lo = rbase < 0 ? -rbase : 0, ph_hi = rbase + S - 1 > 31 ? 31 - rbase : S - 1;
             const long base = (long)co * a.y_cs + (long)q0w * S;
-            for (int m = lane; m < nq * S; m += 64) {
+            for (int m = lane; m < ((PS_ABL & 256) ? (nq * S == 12345 ? 1 : 0) : nq * S); m += 64) {
                 const int ql = (int)__umulhi((unsigned)m, magic), ph = m - ql * S;
                 if (ph < ph_lo || ph > ph_hi) continue;
                 const int row = rbase + ph;
