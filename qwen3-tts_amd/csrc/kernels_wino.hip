@@ -43,6 +43,10 @@ namespace hipvoc {
 static constexpr int WN_BK = 16;      // input channels per K stage
 static constexpr int WN_NT = 128;     // tiles per workgroup (4 waves x 32)
 static constexpr int WN_PTS = 8;
+// Compile-time switches of the experiments behind DESIGN.md section 4b (tools/build_variants.sh builds libraries that differ
+// in them; the defaults are what was measured best): VALU / DS instructions per sched_group (WN_VG / WN_DG), per-lane masks
+// instead of the zero page (WN_MASK / WN_ZP), depth of the input pipeline (WN_DD), the DMA by builtin instead of inline asm
+// (WN_ASMDMA), default workgroup shapes, timing-only ablation bits (PS_ABL).
 #ifndef WN_VG
 #define WN_VG 8
 #endif
@@ -60,9 +64,6 @@ static constexpr int WN_PTS = 8;
 #endif
 #ifndef WN_MODE_DEFAULT
 #define WN_MODE_DEFAULT 5
-#endif
-#ifndef WN_KATTR
-#define WN_KATTR
 #endif
 #ifndef PS_ABL
 #define PS_ABL 0   // timing-only ablation bits (results are wrong with any set)
@@ -129,7 +130,7 @@ __device__ __forceinline__ void wn_dma16_s(const float *sbase, unsigned voff_byt
 
 // SN: the conv has a SnakeBeta prologue (a.sn_a / a.sn_ib), applied to the inputs as they are read from LDS
 template <int D, bool SN, int RT, int RH>
-__global__ __launch_bounds__((WinoGeom<D, RT, RH>::NTH), (RT * RH == 1 ? 2 : 1)) WN_KATTR void wino_conv7_kernel(ConvGemmArgs a, int wg_per_unit, int n_tiles) {
+__global__ __launch_bounds__((WinoGeom<D, RT, RH>::NTH), (RT * RH == 1 ? 2 : 1)) void wino_conv7_kernel(ConvGemmArgs a, int wg_per_unit, int n_tiles) {
     using GEO = WinoGeom<D, RT, RH>;
     constexpr int BN = GEO::BN, WN_WBUF = GEO::WBUF;
     constexpr int NTH = GEO::NTH, XW = GEO::XW, XP = GEO::XP, XBUF = GEO::XBUF, WP = GEO::WP, xw4 = XW / 4;
