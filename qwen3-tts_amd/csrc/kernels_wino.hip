@@ -745,23 +745,26 @@ __global__ __launch_bounds__((PsGeom<D, RT, NTG, BK>::NTH), (NTG == 2 ? 2 : 1)) 
 // tiles of 32 rows x 32 tiles and 4 x RT accumulator tiles: (RT, RW) = (2, 2) -> 128 rows, 8 waves, two per SIMD; (1, 3) ->
 // 96 rows, 12 waves, three per SIMD (N = 288 of the last block, whose time goes into its stores).
 static constexpr int WT_PTS = 4;
-static constexpr int WT_XW = 3 * WN_NT + 8;           // window: positions 3 T0 + sh (floored to 4) .. + 3*128 + 3
 
-template <int RT, int RW>
+// NTG = tile groups of 32 tiles per workgroup: 4, or 3 (96 tiles: a unit of 85 tiles -- block 0's 256 input steps -- fills 89 % of
+// such a workgroup instead of 66 % of a 128-tile one)
+template <int RT, int RW, int NTG>
 struct TconvGeom {
-    static constexpr int NTH = 4 * RW * 64;
+    static constexpr int NTH = NTG * RW * 64;
+    static constexpr int NT = 32 * NTG;                                      // tiles per workgroup
     static constexpr int BN = 32 * RT * RW;                                  // rows per workgroup
-    static constexpr int XP = (WN_BK * (WT_XW / 4) + NTH - 1) / NTH;
+    static constexpr int XW = 3 * NT + 8;                                    // window: positions 3 T0 + sh (floored to 4) .. + 3 NT + 3
+    static constexpr int XP = (WN_BK * (XW / 4) + NTH - 1) / NTH;
     static constexpr int XBUF = XP * NTH * 4;
     static constexpr int WF4 = WT_PTS * WN_BK * BN / 4;                      // float4 of the weight tiles of one block
     static constexpr int WP = (WF4 + NTH - 1) / NTH;
     static constexpr int WBUF = WP * NTH * 4;
 };
 
-template <bool SN, int RT, int RW>
-__global__ __launch_bounds__((TconvGeom<RT, RW>::NTH), 1) void wino_tconv_kernel(ConvGemmArgs a, int wg_per_unit, int n_tiles) {
-    using GEO = TconvGeom<RT, RW>;
-    constexpr int NTH = GEO::NTH, BN = GEO::BN, XW = WT_XW, XP = GEO::XP, XBUF = GEO::XBUF, WP = GEO::WP, WBUF = GEO::WBUF, xw4 = XW / 4;
+template <bool SN, int RT, int RW, int NTG>
+__global__ __launch_bounds__((TconvGeom<RT, RW, NTG>::NTH), 1) void wino_tconv_kernel(ConvGemmArgs a, int wg_per_unit, int n_tiles) {
+    using GEO = TconvGeom<RT, RW, NTG>;
+    constexpr int NTH = GEO::NTH, BN = GEO::BN, XW = GEO::XW, XP = GEO::XP, XBUF = GEO::XBUF, WP = GEO::WP, WBUF = GEO::WBUF, xw4 = XW / 4;
     extern __shared__ __attribute__((aligned(16))) float smem_all[];
     float *Pm = smem_all;                                   // [4][BN] per-row parameters: bias | - | psn_a | psn_ib
     float *Sp = smem_all + 4 * BN;                          // [Cin][2] (SN)
@@ -774,12 +777,12 @@ __global__ __launch_bounds__((TconvGeom<RT, RW>::NTH), 1) void wino_tconv_kernel
     const int nt = id % n_tiles;
     const int pt = id / n_tiles;
     const int unit = pt / wg_per_unit;
-    const int T0 = (pt - unit * wg_per_unit) * WN_NT;
+    const int T0 = (pt - unit * wg_per_unit) * GEO::NT;
     const int n0 = nt * BN;
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l31 = lane & 31, h = lane >> 5;
-    const int tw = wave & 3, rw = wave >> 2;                // tile group, wave-row
+    const int tw = wave % NTG, rw = wave / NTG;             // tile group, wave-row
     const float *xu = a.x + (long)unit * a.x_us;
     const int CinP = ((a.Cin + 31) / 32) * 32;
     const int ncb = a.Cin / WN_BK;
@@ -989,6 +992,17 @@ static bool wino_tconv_rows128(const ConvGemmArgs &a) {
     return wgs > 192;
 }
 
+// ... and 96-tile workgroups (12 waves x one row tile, 128 rows) where they fill visibly better than 128-tile ones
+static bool wino_tconv_tiles96(const ConvGemmArgs &a) {
+    if (!wino_tconv_rows128(a)) return false;
+    const char *e = getenv("HIPVOC_WINO_TCONV_NT96");
+    if (e && atoi(e) == 0) return false;
+    if (e && atoi(e) == 2) return true;                      // (experiment: always)
+    const long n_tl = (a.M + 2) / 3;
+    const double f128 = (double)n_tl / (double)(((n_tl + 127) / 128) * 128), f96 = (double)n_tl / (double)(((n_tl + 95) / 96) * 96);
+    return f96 > f128 + 0.1;
+}
+
 bool wino_selected(const ConvGemmArgs &a) {
     if (wino_unit_selected(a)) return true;
     if (!a.ww || a.wb || a.w2) return false;
@@ -1012,9 +1026,9 @@ const char *wino_kernel_name(const ConvGemmArgs &a) {      // as rocprofv3 print
         return a.shift_step == 1 ? "wino_ps_kernel<1,3,true,4,16>" : a.shift_step == 3 ? "wino_ps_kernel<3,3,true,4,16>" : "wino_ps_kernel<9,3,true,4,16>";
     }
     if (wino_tconv_selected(a)) {
-        const bool big = wino_tconv_rows128(a);
-        if (a.sn_a) return big ? "wino_tconv_kernel<true,2,2>" : "wino_tconv_kernel<true,1,3>";
-        return big ? "wino_tconv_kernel<false,2,2>" : "wino_tconv_kernel<false,1,3>";
+        const bool big = wino_tconv_rows128(a), t96 = wino_tconv_tiles96(a);
+        if (a.sn_a) return t96 ? "wino_tconv_kernel<true,1,4,3>" : big ? "wino_tconv_kernel<true,2,2,4>" : "wino_tconv_kernel<true,1,3,4>";
+        return t96 ? "wino_tconv_kernel<false,1,4,3>" : big ? "wino_tconv_kernel<false,2,2,4>" : "wino_tconv_kernel<false,1,3,4>";
     }
     static char names[2][3][5][44];
     const int di = a.shift_step == 1 ? 0 : a.shift_step == 3 ? 1 : 2, sn = a.sn_a ? 1 : 0, mode = sn && (wino_rt() == 3 || wino_rt() == 5) ? 1 : wino_rt();
@@ -1093,11 +1107,11 @@ static hipError_t wino_ps_launch_one(const ConvGemmArgs &a, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <bool SN, int RT, int RW>
+template <bool SN, int RT, int RW, int NTG>
 static hipError_t wino_tconv_launch_one(const ConvGemmArgs &a, hipStream_t s) {
-    using GEO = TconvGeom<RT, RW>;
+    using GEO = TconvGeom<RT, RW, NTG>;
     const int n_tl = (a.M + 2) / 3;                          // tiles of three input steps
-    const int wg_per_unit = (n_tl + WN_NT - 1) / WN_NT;
+    const int wg_per_unit = (n_tl + GEO::NT - 1) / GEO::NT;
     const int n_tiles = a.N / GEO::BN;
     const long grid = (long)wg_per_unit * a.units * n_tiles;
     if (grid > 0x7fffffffL) return hipErrorInvalidValue;
@@ -1113,11 +1127,11 @@ static hipError_t wino_tconv_launch_one(const ConvGemmArgs &a, hipStream_t s) {
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 64 && !done[dev]) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(wino_tconv_kernel<SN, RT, RW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(wino_tconv_kernel<SN, RT, RW, NTG>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         done[dev] = true;
     }
-    hipLaunchKernelGGL((wino_tconv_kernel<SN, RT, RW>), dim3((unsigned)grid), dim3(GEO::NTH), lds, s, a, wg_per_unit, n_tiles);
+    hipLaunchKernelGGL((wino_tconv_kernel<SN, RT, RW, NTG>), dim3((unsigned)grid), dim3(GEO::NTH), lds, s, a, wg_per_unit, n_tiles);
     return hipGetLastError();
 }
 
@@ -1135,8 +1149,9 @@ hipError_t launch_wino_conv7(const ConvGemmArgs &a, hipStream_t s) {
         if ((a.x_cs & 3) || (a.x_us & 3) || ((uintptr_t)a.x & 15) || ((uintptr_t)a.ww & 15) || (a.NP & 3) || (a.sn_a && !a.sn_ib) || a.Cin > 4096)
             return hipErrorInvalidValue;
         const bool sn = a.sn_a != nullptr;
-        if (wino_tconv_rows128(a)) return sn ? wino_tconv_launch_one<true, 2, 2>(a, s) : wino_tconv_launch_one<false, 2, 2>(a, s);
-        return sn ? wino_tconv_launch_one<true, 1, 3>(a, s) : wino_tconv_launch_one<false, 1, 3>(a, s);
+        if (wino_tconv_tiles96(a)) return sn ? wino_tconv_launch_one<true, 1, 4, 3>(a, s) : wino_tconv_launch_one<false, 1, 4, 3>(a, s);
+        if (wino_tconv_rows128(a)) return sn ? wino_tconv_launch_one<true, 2, 2, 4>(a, s) : wino_tconv_launch_one<false, 2, 2, 4>(a, s);
+        return sn ? wino_tconv_launch_one<true, 1, 3, 4>(a, s) : wino_tconv_launch_one<false, 1, 3, 4>(a, s);
     }
     // host-side shape checks: what the kernel's 16-byte accesses assume
     if ((a.x_cs & 3) || (a.x_us & 3) || ((uintptr_t)a.x & 15) || ((uintptr_t)a.ww & 15) || (a.NP & 3) || a.Lin < 1 ||
