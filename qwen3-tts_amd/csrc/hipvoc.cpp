@@ -123,6 +123,7 @@ struct Ctx {
     bool profile = false;
     bool fuse_res = true;
     bool post_snake = true;
+    bool fin_post = true;         // the final SnakeBeta in the last residual unit's epilogue (HIPVOC_FIN_POST)
     bool phase_major = true;   // transposed-conv rows phase-major (HIPVOC_PHASE_MAJOR=0: channel-major)
     bool packed = true;        // bf16 mode: GEMM-to-GEMM tensors of the decoder stack exchanged as packed bf16 (HIPVOC_PACKED=0: fp32)
     bool wino_tconv = true;    // fp32 mode: the decoder blocks' transposed convs by F(3,2) (HIPVOC_WINO_TCONV=0: direct)
@@ -964,6 +965,9 @@ static std::unique_ptr<Plan> build_plan(Ctx *c, int G, int T, bool debug, char *
     // per row tile (up to 48x for block 0).  Debug plans (stage taps want the raw tensors) keep it in the
     // consumer.
     const bool post_snake = !debug && c->post_snake;
+    // Likewise the final SnakeBeta (g7) is applied by the last residual unit, whose raw output nothing else reads, and
+    // final_conv_kernel filters an activated tensor (HIPVOC_FIN_POST=0: in the final kernel, 2.5 evaluations per element).
+    const Snake *fin_post = (post_snake && c->fin_post && c->fin.ntaps == 7) ? &c->fin_snake : nullptr;
     // bf16 mode: every tensor of the decoder stack that is only consumed as a GEMM operand is
     // exchanged as packed bf16 with the consumer's SnakeBeta applied by its producer (ConvGemmArgs::xb / yb); the
     // residual stream stays fp32.  Needs every channel count of the stack to be a multiple of 8.
@@ -1001,7 +1005,7 @@ static std::unique_ptr<Plan> build_plan(Ctx *c, int G, int T, bool debug, char *
             for (int u = 0; u < 3; u++) {
                 const Ctx::Res &ru = blk.res[u];
                 const bool last = u == 2 && bi + 1 == c->blocks.size();      // feeds the final conv: fp32 only
-                const Snake *next = u < 2 ? &blk.res[u + 1].s1 : (last ? nullptr : &c->blocks[bi + 1].s);
+                const Snake *next = u < 2 ? &blk.res[u + 1].s1 : (last ? fin_post : &c->blocks[bi + 1].s);
                 const bool need_f32 = u < 2 || last || debug;                // the residual stream goes on / the final conv
                 if (fused_blk) {
                     unsigned short *ybo = last ? nullptr : pk[pc ^ 1];
@@ -1055,7 +1059,7 @@ static std::unique_ptr<Plan> build_plan(Ctx *c, int G, int T, bool debug, char *
             b.mark(st++, cur, C, L, Lp);
             for (int u = 0; u < 3; u++) {
                 const Ctx::Res &ru = blk.res[u];
-                const Snake *post = (post_snake && u == 2 && bi + 1 < c->blocks.size()) ? &c->blocks[bi + 1].s : nullptr;
+                const Snake *post = u != 2 ? nullptr : bi + 1 < c->blocks.size() ? (post_snake ? &c->blocks[bi + 1].s : nullptr) : fin_post;
                 if (wino_unit) {
                     const Snake *nxt = u < 2 ? &blk.res[u + 1].s1 : post;
                     b.res_unit_wino(ru_names[ni], ru.c1, ru.c2, ru.s2, snk, cur, L, Lp, t1, nxt, u < 2 ? snk_other : nullptr);
@@ -1084,7 +1088,8 @@ static std::unique_ptr<Plan> build_plan(Ctx *c, int G, int T, bool debug, char *
     // g7: final snake + conv -> 1 channel + clamp, written straight to the caller's buffer
     if (c->fin.ntaps == 7) {
         const Gemm &g = c->fin;
-        const float *x = cur, *w = c->fin_w_raw, *bias = g.bias, *sa = c->fin_snake.ea, *sib = c->fin_snake.ib;
+        const bool act_in = fin_post && !c->blocks.empty();      // cur = fin_snake(out of the last unit)
+        const float *x = cur, *w = c->fin_w_raw, *bias = g.bias, *sa = act_in ? nullptr : c->fin_snake.ea, *sib = act_in ? nullptr : c->fin_snake.ib;
         int Cf = g.Cin, GG = G, LL = L, LLp = Lp;
         Ctx *cc = c;
         b.add("final_conv7", "final_conv_kernel<7>", (double)G * L * g.Cin * g.ntaps, [=](hipStream_t s) {
@@ -1428,6 +1433,7 @@ static void *load_impl(const char *weights_path, int device_id, int dtype, int u
     if (const char *pf = getenv("HIPVOC_PROFILE")) c->profile = atoi(pf) != 0;
     if (const char *fz = getenv("HIPVOC_FUSE")) c->fuse_res = atoi(fz) != 0;
     if (const char *ps = getenv("HIPVOC_POST_SNAKE")) c->post_snake = atoi(ps) != 0;
+    if (const char *ps = getenv("HIPVOC_FIN_POST")) c->fin_post = atoi(ps) != 0;
     if (const char *ps = getenv("HIPVOC_DUAL")) c->dual_out = atoi(ps);
     if (const char *ps = getenv("HIPVOC_PACKED")) c->packed = atoi(ps) != 0;
     if (const char *ps = getenv("HIPVOC_PHASE_MAJOR")) c->phase_major = atoi(ps) != 0;

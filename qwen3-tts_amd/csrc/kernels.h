@@ -95,6 +95,9 @@ const char *wino_kernel_name(const ConvGemmArgs &a);
 bool gemmd_selected(const ConvGemmArgs &a);           // kernels_wino.hip: large 1-tap GEMMs with both operands staged by LDS-DMA
 hipError_t launch_gemmd(const ConvGemmArgs &a, hipStream_t s);
 const char *gemmd_kernel_name(const ConvGemmArgs &a);
+bool gemmds_selected(const ConvGemmArgs &a);          // kernels_wino.hip: the same GEMMs on a small launch (deep LDS-DMA pipeline, 1-2 waves per workgroup)
+hipError_t launch_gemmds(const ConvGemmArgs &a, hipStream_t s);
+const char *gemmds_kernel_name(const ConvGemmArgs &a);
 size_t conv_gemm_bf16_lds_bytes(const ConvGemmArgs &a);
 namespace detail {
 void conv_gemm_geometry(const ConvGemmArgs &a, int &HL, int &XW, int bm = 256);   // halo (left, multiple of 4) and LDS tile width for bm positions

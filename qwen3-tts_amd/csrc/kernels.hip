@@ -379,6 +379,7 @@ using detail::conv_gemm_launch_tn;
 const char *conv_gemm_kernel_name(const ConvGemmArgs &a) {
     if (a.wb) return conv_gemm_bf16_kernel_name(a);
     if (wino_selected(a)) return wino_kernel_name(a);
+    if (gemmds_selected(a)) return gemmds_kernel_name(a);
     if (gemm1_selected(a)) return gemm1_kernel_name(a);
     if (convs_selected(a)) return convs_kernel_name(a);
     if (gemmd_selected(a)) return gemmd_kernel_name(a);
@@ -422,6 +423,7 @@ static hipError_t conv_gemm_launch_one(const ConvGemmArgs &a, int HL, int XW, in
 hipError_t launch_conv_gemm(const ConvGemmArgs &a_in, hipStream_t s) {
     if (a_in.wb) return launch_conv_gemm_bf16(a_in, s);
     if (wino_selected(a_in)) return launch_wino_conv7(a_in, s);
+    if (gemmds_selected(a_in)) return launch_gemmds(a_in, s);
     if (gemm1_selected(a_in)) return launch_gemm1(a_in, s);
     if (convs_selected(a_in)) return launch_convs(a_in, s);
     if (gemmd_selected(a_in)) return launch_gemmd(a_in, s);
@@ -1094,6 +1096,8 @@ hipError_t launch_dwconv_ln(const float *x, float *y, const float *dw_w, const f
 // Final stage: SnakeBeta -> causal conv C -> 1 channel (K <= 9 taps) -> clamp[-1,1].
 // HBM-bound (reads C floats per output sample): no LDS, every thread produces 4 consecutive samples
 // and recomputes the K-1 halo activations it needs from aligned float4 loads (neighbours' loads hit L1/L2).
+// sn_a == null: x is already activated (the last residual unit applied the final SnakeBeta in its epilogue, once per
+// element instead of 2.5 times here) and the kernel is a plain 7-tap filter over C rows.
 // -------------------------------------------------------------------------------------------------
 template <int K>
 __global__ __launch_bounds__(256) void final_conv_kernel(const float *x, float *out, const float *w /*[C][K]*/,
@@ -1114,21 +1118,25 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const float *x, float *
     float b0 = bias ? bias[0] : 0.0f;
 #pragma unroll
     for (int i = 0; i < NO; i++) acc[i] = b0;
+    const bool sn = sn_a != nullptr;                  // (uniform)
+#pragma unroll 4
     for (int c = 0; c < C; c++) {
         const float *xr = xu + (long)c * cs;
         float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
         float4 v0 = t >= 8 ? *reinterpret_cast<const float4 *>(xr + t - 8) : z;
         float4 v1 = t >= 4 ? *reinterpret_cast<const float4 *>(xr + t - 4) : z;
         float4 v2 = *reinterpret_cast<const float4 *>(xr + t);
-        const f32x2 sa = (f32x2)(sn_a[c]), sib = (f32x2)(sn_ib[c]);
         float sv[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
+        if (sn) {
+            const f32x2 sa = (f32x2)(sn_a[c]), sib = (f32x2)(sn_ib[c]);
 #pragma unroll
-        for (int i = 2; i < 12; i += 2) {             // (sv[0], sv[1] are never read: K - 1 <= 6)
-            f32x2 s2 = snake_beta2(mk2(sv[i], sv[i + 1]), sa, sib);
-            int pos = t - 8 + i;
-            sv[i] = (pos >= 0 && pos < L) ? s2.x : 0.0f;            // zero padding applies to the activation output
-            sv[i + 1] = (pos + 1 >= 0 && pos + 1 < L) ? s2.y : 0.0f;
-        }
+            for (int i = 2; i < 12; i += 2) {         // (sv[0], sv[1] are never read: K - 1 <= 6)
+                f32x2 s2 = snake_beta2(mk2(sv[i], sv[i + 1]), sa, sib);
+                int pos = t - 8 + i;
+                sv[i] = (pos >= 0 && pos < L) ? s2.x : 0.0f;        // zero padding applies to the activation output
+                sv[i + 1] = (pos + 1 >= 0 && pos + 1 < L) ? s2.y : 0.0f;
+            }
+        }                                             // else: positions < 0 are the zeros above; positions >= L only reach samples >= L
 #pragma unroll
         for (int j = 0; j < K; j++) {
             float wv = w[c * K + j];

@@ -1003,6 +1003,29 @@ static bool wino_tconv_tiles96(const ConvGemmArgs &a) {
     return f96 > f128 + 0.1;
 }
 
+// Workgroup shape of a transposed conv: {RT, RW, NTG}.  Large launches: the rules above (measured at 64 units).  Small launches
+// (a single utterance: the default shape's grid is at most HIPVOC_WINO_TCONV_SMALL workgroups, default 400; 0: never) pick the
+// cheapest of the instantiated shapes by rounds x work per SIMD: a grid of 128 12-wave workgroups leaves half the chip idle, one
+// of 324 runs two rounds for 1.3.  The 64-row shapes (RT 1, RW 2: 6 or 8 waves) exist for this.  Per output element every shape
+// runs the same chain of MFMAs and the same transforms: bit-identical (the batch == single tests cover it).
+struct TconvShape { int rt, rw, ntg; };
+static TconvShape wino_tconv_shape(const ConvGemmArgs &a) {
+    const TconvShape dflt = wino_tconv_tiles96(a) ? TconvShape{1, 4, 3} : wino_tconv_rows128(a) ? TconvShape{2, 2, 4} : TconvShape{1, 3, 4};
+    const char *e = getenv("HIPVOC_WINO_TCONV_SMALL");
+    const long max_wgs = e ? atol(e) : 400;
+    const long n_tl = (a.M + 2) / 3;
+    auto wgs = [&](const TconvShape &t) { return ((n_tl + 32 * t.ntg - 1) / (32 * t.ntg)) * (long)a.units * (a.N / (32 * t.rt * t.rw)); };
+    if (max_wgs <= 0 || wgs(dflt) > max_wgs) return dflt;
+    auto cost = [&](const TconvShape &t) {                 // rounds over 256 CUs (one workgroup each) x MFMAs per SIMD and channel block
+        return ((wgs(t) + 255) / 256) * t.rt * ((t.ntg * t.rw + 3) / 4);
+    };
+    static const TconvShape cand[] = {{1, 2, 3}, {1, 2, 4}, {1, 3, 4}, {1, 4, 3}, {2, 2, 4}};
+    TconvShape best = dflt;
+    for (const TconvShape &t : cand)
+        if (a.N % (32 * t.rt * t.rw) == 0 && cost(t) < cost(best)) best = t;
+    return best;
+}
+
 bool wino_selected(const ConvGemmArgs &a) {
     if (wino_unit_selected(a)) return true;
     if (!a.ww || a.wb || a.w2) return false;
@@ -1026,9 +1049,11 @@ const char *wino_kernel_name(const ConvGemmArgs &a) {      // as rocprofv3 print
         return a.shift_step == 1 ? "wino_ps_kernel<1,3,true,4,16>" : a.shift_step == 3 ? "wino_ps_kernel<3,3,true,4,16>" : "wino_ps_kernel<9,3,true,4,16>";
     }
     if (wino_tconv_selected(a)) {
-        const bool big = wino_tconv_rows128(a), t96 = wino_tconv_tiles96(a);
-        if (a.sn_a) return t96 ? "wino_tconv_kernel<true,1,4,3>" : big ? "wino_tconv_kernel<true,2,2,4>" : "wino_tconv_kernel<true,1,3,4>";
-        return t96 ? "wino_tconv_kernel<false,1,4,3>" : big ? "wino_tconv_kernel<false,2,2,4>" : "wino_tconv_kernel<false,1,3,4>";
+        static char tn[2][3][5][5][36];
+        const TconvShape t = wino_tconv_shape(a);
+        char *n = tn[a.sn_a ? 1 : 0][t.rt][t.rw][t.ntg];
+        if (!n[0]) snprintf(n, 36, "wino_tconv_kernel<%s,%d,%d,%d>", a.sn_a ? "true" : "false", t.rt, t.rw, t.ntg);
+        return n;
     }
     static char names[2][3][5][44];
     const int di = a.shift_step == 1 ? 0 : a.shift_step == 3 ? 1 : 2, sn = a.sn_a ? 1 : 0, mode = sn && (wino_rt() == 3 || wino_rt() == 5) ? 1 : wino_rt();
@@ -1149,9 +1174,15 @@ hipError_t launch_wino_conv7(const ConvGemmArgs &a, hipStream_t s) {
         if ((a.x_cs & 3) || (a.x_us & 3) || ((uintptr_t)a.x & 15) || ((uintptr_t)a.ww & 15) || (a.NP & 3) || (a.sn_a && !a.sn_ib) || a.Cin > 4096)
             return hipErrorInvalidValue;
         const bool sn = a.sn_a != nullptr;
-        if (wino_tconv_tiles96(a)) return sn ? wino_tconv_launch_one<true, 1, 4, 3>(a, s) : wino_tconv_launch_one<false, 1, 4, 3>(a, s);
-        if (wino_tconv_rows128(a)) return sn ? wino_tconv_launch_one<true, 2, 2, 4>(a, s) : wino_tconv_launch_one<false, 2, 2, 4>(a, s);
-        return sn ? wino_tconv_launch_one<true, 1, 3, 4>(a, s) : wino_tconv_launch_one<false, 1, 3, 4>(a, s);
+        const TconvShape t = wino_tconv_shape(a);
+#define WT_GO(RT_, RW_, NTG_) if (t.rt == RT_ && t.rw == RW_ && t.ntg == NTG_) return sn ? wino_tconv_launch_one<true, RT_, RW_, NTG_>(a, s) : wino_tconv_launch_one<false, RT_, RW_, NTG_>(a, s)
+        WT_GO(2, 2, 4);
+        WT_GO(1, 3, 4);
+        WT_GO(1, 4, 3);
+        WT_GO(1, 2, 3);
+        WT_GO(1, 2, 4);
+#undef WT_GO
+        return hipErrorInvalidValue;
     }
     // host-side shape checks: what the kernel's 16-byte accesses assume
     if ((a.x_cs & 3) || (a.x_us & 3) || ((uintptr_t)a.x & 15) || ((uintptr_t)a.ww & 15) || (a.NP & 3) || a.Lin < 1 ||
@@ -1328,6 +1359,162 @@ hipError_t launch_gemmd(const ConvGemmArgs &a, hipStream_t s) {
         case 3: return gemmd_launch_one<3, 8>(a, s);
         default: return gemmd_launch_one<4, 8>(a, s);
     }
+}
+
+// -------------------------------------------------------------------------------------------------------------------------
+// gemm_dmas_kernel<TN, NW, DP>: the same GEMM for SMALL launches (one utterance: BASELINE configs[1]).  There a layer is a few dozen
+// workgroups, one wave per SIMD, and nothing on the CU hides a memory round trip: gemm1_kernel's two-stage pipeline of 64-channel
+// stages spends 2.2 us per stage where its 32 MFMAs take 0.85 (o_proj, K = 1024: 36 us).  Here the 16-channel stages of
+// gemm_dma_kernel are DP deep in flight (LDS-DMA needs no registers to hold them), so after the first round trip the wave's MFMA chain
+// -- 64 cycles per k pair, the floor of any kernel that sums in this order -- runs without waiting, and a workgroup is NW <= 2 waves
+// of 32 positions (more, shorter workgroups on the idle chip).  Same MFMA chain and epilogue: bit-identical to gemm_dma_kernel,
+// gemm1_kernel and conv_gemm_kernel (test_gemm_dma_bitwise), so the choice may depend on the launch size.
+template <int TN, int NW, int DP>
+__global__ __launch_bounds__(64 * NW, 1) void gemm_dmas_kernel(ConvGemmArgs a, int tiles_per_unit, int n_tiles) {
+    constexpr int NTH = 64 * NW, BM = 32 * NW, BN = 32 * TN, GK = 16;
+    constexpr int XBUF = GK * BM, WBUF = GK * BN, XPT = GK * BM / 4 / NTH, WPT = GK * BN / 4 / NTH;
+    constexpr int PPS = XPT + WPT;                          // DMA pieces per thread and stage: the same for every thread
+    static_assert(XPT == 2 && WPT * NTH * 4 == GK * BN && (DP & (DP - 1)) == 0 && DP >= 4 && PPS * (DP - 2) <= 63, "uniform piece count, vmcnt range");
+    extern __shared__ __attribute__((aligned(16))) float smem_all[];
+    float *Pm = smem_all;                                   // [4][BN] per-row parameters
+    float *Xs = smem_all + 4 * BN;                          // [DP][16][BM]
+    float *Ws = Xs + DP * XBUF;                             // [DP][16][BN]
+
+    const int id = blockIdx.x;                              // (a small launch: no XCD remap -- fewer workgroups than CUs)
+    const int nt = id % n_tiles;
+    const int pt = id / n_tiles;
+    const int unit = pt / tiles_per_unit;
+    const int m0 = (pt - unit * tiles_per_unit) * BM;
+    const int n0 = nt * BN;
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const float *xu = a.x + (long)unit * a.x_us;
+    const int ncb = a.Cin / GK;
+
+    f32x16 acc[TN];
+#pragma unroll
+    for (int i = 0; i < TN; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][r] = 0.0f;
+
+    const int xlim = ((a.Lin + 3) & ~3) - 4;
+    unsigned xvo[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int i = tid + NTH * j, row = i / (BM / 4), c4 = i - row * (BM / 4);
+        int pos = m0 + 4 * c4;
+        pos = pos > xlim ? xlim : pos;
+        xvo[j] = ((unsigned)row * (unsigned)a.x_cs + (unsigned)pos) * 4u;
+    }
+    unsigned wvo[WPT];
+#pragma unroll
+    for (int j = 0; j < WPT; j++) {
+        const int i = tid + NTH * j, wrow = i / (BN / 4), wc4 = i - wrow * (BN / 4);
+        wvo[j] = ((unsigned)wrow * (unsigned)a.NP + (unsigned)wc4 * 4u) * 4u;
+    }
+    auto stage = [&](int cb) {
+        const int buf = cb & (DP - 1);
+        const float *xb = xu + (long)cb * GK * a.x_cs;
+        float *xd = Xs + buf * XBUF + wave * 256;
+        wn_dma16_s(xb, xvo[0], xd);
+        wn_dma16_s(xb, xvo[1], xd + NTH * 4);
+        const float *wb = a.w + ((long)cb * GK) * a.NP + n0;
+#pragma unroll
+        for (int j = 0; j < WPT; j++) wn_dma16_s(wb, wvo[j], Ws + buf * WBUF + wave * 256 + j * (NTH * 4));
+    };
+
+#pragma unroll
+    for (int s = 0; s < DP - 1; s++)
+        if (s < ncb) stage(s);
+    fill_param_table<BN, false>(a, Pm, n0, tid, NTH);
+    // The operands of block cb + 1 are read from LDS into the other register set BEFORE the MFMAs of block cb (one wave per SIMD:
+    // nothing else hides the ds_read latency); so the wait + barrier of iteration cb are for block cb + 1.
+    float av[2][GK / 2][TN], bv[2][GK / 2];
+    const float *ws0 = Ws + l31 + h * BN, *xs0 = Xs + wave * 32 + l31 + h * BM;      // lane bases: pair kk is rows 2 kk + h
+    auto lds_read = [&](const float *ws, const float *xs, int sl, int kk) {            // (kk-dependent part: an immediate offset)
+#pragma unroll
+        for (int i = 0; i < TN; i++) av[sl][kk][i] = ws[2 * kk * BN + i * 32];
+        bv[sl][kk] = xs[2 * kk * BM];
+    };
+    auto step = [&](int cb, int sl) {
+        const bool more = cb + 1 < ncb;
+        if (more) {
+            // issued so far: stages .. cb + DP - 2; vmcnt retires in order: all but the younger ones = stage cb + 1 has landed
+            if (cb + DP - 2 < ncb) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(PPS * (DP - 3)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (cb + DP - 1 < ncb) stage(cb + DP - 1);      // into the buffer of block cb - 1: every wave has read it (the barrier)
+        }
+        // (pinned order: MFMA kk, then the reads of the next block's pair kk -- they return under the following MFMAs, and the
+        // compiler's own lgkmcnt for MFMA kk then never waits for a read issued in this iteration)
+        const int nb = (more ? cb + 1 : cb) & (DP - 1);     // (last block: a harmless re-read instead of a branch per pair)
+        const float *ws = ws0 + nb * WBUF, *xs = xs0 + nb * XBUF;
+#pragma unroll
+        for (int kk = 0; kk < GK / 2; kk++) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TN; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[sl][kk][i], bv[sl][kk], acc[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            lds_read(ws, xs, sl ^ 1, kk);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    if (DP - 2 < ncb) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(PPS * (DP - 2)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+    for (int kk = 0; kk < GK / 2; kk++) lds_read(ws0, xs0, 0, kk);
+    for (int cb = 0; cb < ncb; cb += 2) {                   // (Cin % 32 == 0: an even number of blocks)
+        step(cb, 0);
+        step(cb + 1, 1);
+    }
+
+    float *yu = a.y + (long)unit * a.y_us;
+    const float *ru0 = launder_after(a.res, acc[TN - 1][15]);
+    const float *ru = ru0 ? ru0 + (long)unit * a.y_us : nullptr;
+    float *y2u0 = launder_after(a.y2, acc[TN - 1][15]);
+    float *y2u = y2u0 ? y2u0 + (long)unit * a.y_us : nullptr;
+    const int m = m0 + wave * 32 + l31;
+#pragma unroll
+    for (int i = 0; i < TN; i++) conv_epilogue_tile<BN, false>(a, acc[i], Pm, n0, i * 32 + 4 * h, m, yu, ru, y2u);
+}
+
+// Shape of the small-launch form: HIPVOC_GEMMDS_NW waves (1 or 2; default 2) x TN = 1; used when that grid is at most
+// HIPVOC_GEMMDS_WGS workgroups (default 640; 0 turns the kernel off: gemm1_kernel runs those layers, same bits).
+static int gemmds_nw() {
+    const char *e = getenv("HIPVOC_GEMMDS_NW");
+    return e && atoi(e) == 1 ? 1 : 2;
+}
+
+bool gemmds_selected(const ConvGemmArgs &a) {
+    const char *e = getenv("HIPVOC_GEMMDS_WGS");
+    const long max_wgs = e ? atol(e) : 640;
+    if (max_wgs <= 0 || !gemmd_selected(a) || a.Cin > 65536 || a.Cin % 32) return false;
+    const int bm = 32 * gemmds_nw();
+    return (long)((a.M + bm - 1) / bm) * a.units * (a.NP / 32) <= max_wgs;
+}
+
+const char *gemmds_kernel_name(const ConvGemmArgs &) { return gemmds_nw() == 1 ? "gemm_dmas_kernel<1,1,8>" : "gemm_dmas_kernel<1,2,8>"; }
+
+template <int TN, int NW, int DP>
+static hipError_t gemmds_launch_one(const ConvGemmArgs &a, hipStream_t s) {
+    constexpr int BM = 32 * NW;
+    const int tiles_per_unit = (a.M + BM - 1) / BM, n_tiles = a.NP / (32 * TN);
+    const long grid = (long)tiles_per_unit * a.units * n_tiles;
+    if (grid > 0x7fffffffL) return hipErrorInvalidValue;
+    const size_t lds = sizeof(float) * (4 * 32 * TN + DP * 16 * (BM + 32 * TN));
+    static_assert(sizeof(float) * (4 * 32 * TN + DP * 16 * (BM + 32 * TN)) <= 64 * 1024, "static LDS limit: no attribute call needed");
+    hipLaunchKernelGGL((gemm_dmas_kernel<TN, NW, DP>), dim3((unsigned)grid), dim3(64 * NW), lds, s, a, tiles_per_unit, n_tiles);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemmds(const ConvGemmArgs &a, hipStream_t s) {
+    if (!gemmds_selected(a)) return hipErrorInvalidValue;
+    if (a.M <= 0) return hipSuccess;
+    // what the kernel's 16-byte DMA pieces and 32-bit byte offsets assume
+    if ((a.x_cs & 3) || (a.x_us & 3) || ((uintptr_t)a.x & 15) || ((uintptr_t)a.w & 15) || (a.NP & 31) || a.Lin < 1 ||
+        16.0 * (double)a.x_cs * 4.0 + 4.0 * (double)a.Lin >= 4294967296.0 || 16.0 * (double)a.NP * 4.0 >= 4294967296.0)
+        return hipErrorInvalidValue;
+    return gemmds_nw() == 1 ? gemmds_launch_one<1, 1, 8>(a, s) : gemmds_launch_one<1, 2, 8>(a, s);
 }
 
 }  // namespace hipvoc

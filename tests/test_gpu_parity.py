@@ -401,7 +401,8 @@ def test_winograd_workgroup_shapes_agree(pkg, synth, monkeypatch):
 def test_gemm_dma_bitwise(pkg, synth, monkeypatch):
     """gemm_dma_kernel (the large 1-tap GEMMs with both operands staged by LDS-DMA) runs the same MFMA chain per output as
     conv_gemm_kernel and gemm1_kernel: with it off (HIPVOC_GEMMD=0) the waveform is the same bit for bit, at a large launch
-    (64 units: it is selected for the 1x1 convs) and at a small one (2 units: gemm1_kernel takes those layers either way)."""
+    (64 units: it is selected for the 1x1 convs) and at a small one (2 units: its small-launch form gemm_dmas_kernel against
+    gemm1_kernel)."""
     cfg = synth.FULL
     voc_for(pkg, synth, "FULL", 0, 64)
     path = os.path.join(tempfile.gettempdir(), "hipvoc_test_FULL_0.safetensors")
@@ -414,10 +415,14 @@ def test_gemm_dma_bitwise(pkg, synth, monkeypatch):
         big = v.synthesize_batch(codes) if hasattr(v, "synthesize_batch") else [v.synthesize(c) for c in codes]
         names = {k.split("|")[1] for k in v.last_profile()}
         small = v.synthesize(codes[0])
+        small_names = {k.split("|")[1] for k in v.last_profile()}
         v.close()
-        outs[on] = (big, small, names)
+        outs[on] = (big, small, names, small_names)
     assert any(n.startswith("gemm_dma_kernel") for n in outs["1"][2]), outs["1"][2]
     assert not any(n.startswith("gemm_dma_kernel") for n in outs["0"][2]), outs["0"][2]
+    # the small launch: gemm_dmas_kernel (deep LDS-DMA pipeline) for the transformer's projections, gemm1_kernel with it off
+    assert any(n.startswith("gemm_dmas_kernel") for n in outs["1"][3]), outs["1"][3]
+    assert not any(n.startswith("gemm_dma") for n in outs["0"][3]) and any(n.startswith("gemm1_kernel") for n in outs["0"][3]), outs["0"][3]
     for x, y in zip(outs["1"][0], outs["0"][0]):
         assert np.array_equal(np.asarray(x).view(np.uint32), np.asarray(y).view(np.uint32))
     assert np.array_equal(outs["1"][1].view(np.uint32), outs["0"][1].view(np.uint32))
