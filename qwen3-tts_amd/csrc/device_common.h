@@ -88,11 +88,27 @@ __device__ __forceinline__ float gelu_tanh(float v) {
 //   unfused: [4][BN]  bias | rscale | psn_a | psn_ib      (entries of absent vectors are never read)
 //   fused:   [6][BN]  bias1 | sn2_a | sn2_ib | bias2 | psn_a | psn_ib
 // All source vectors are zero-padded by the loader, so padded rows read zeros.
+// Octet-interleaved rows of a transposed conv (ConvGemmArgs::pm == 2; stride S = 4 or 8, Cout % 8 == 0).  With phase-major rows a
+// workgroup's rows are ONE phase of its channels: every 4- or 8-byte store lands in a different cache line, whose other phases come
+// from other workgroups at other times (bf16 mode, b2's trans-conv: 7.9 GB written for 3.0 GB of tensors).  Here the rows are ordered
+// so that the accumulator layout itself is the memory layout: 8 S consecutive rows are all phases of 8 channels, and in the 32-row
+// tile ti of that group the lane half h holds, in registers r = 0..15, channel r >> 1 at phase (S/2) h + 2 ti + (r & 1) -- the
+// fp32 tensor gets 8-byte stores that tile whole lines across the wave (lane m, half h), the packed bf16 tensor whole 16-byte
+// elements (8 channels of one position), two adjacent ones per lane.  No cross-lane traffic; the loader packs the weights so
+// (kernels.h: tconv_oi_n, the inverse map).
+// row n -> (channel, phase):
+__device__ __forceinline__ void tconv_oi_row(int n, int S, int &c, int &ph) {
+    const int sup = n / (8 * S), t = n - sup * 8 * S, ti = t >> 5, rho = t & 31;
+    const int h = (rho >> 2) & 1, r = (rho & 3) + 4 * (rho >> 3);
+    c = 8 * sup + (r >> 1);
+    ph = (S >> 1) * h + 2 * ti + (r & 1);
+}
 template <int BN, bool FUSE>
 __device__ __forceinline__ void fill_param_table(const ConvGemmArgs &a, float *Pm, int n0, int tid, int nthreads) {
     for (int row = tid; row < BN; row += nthreads) {
         const int n = n0 + row;
-        const int co = a.S > 1 ? (a.pm ? n % (a.N / a.S) : n / a.S) : n;
+        int co = a.S > 1 ? (a.pm ? n % (a.N / a.S) : n / a.S) : n;
+        if (a.S > 1 && a.pm == 2) { int ph_; tconv_oi_row(n, a.S, co, ph_); }
         if constexpr (FUSE) {
             Pm[0 * BN + row] = a.bias[co];
             Pm[1 * BN + row] = a.sn2_a[co];
@@ -122,9 +138,65 @@ __device__ __forceinline__ uint2 pack4_bf16(float a, float b, float c, float d) 
 // as bf16 in channel-group-major form.  For S == 1 a lane's four rows (r&3) are half of a channel group: one 8-byte
 // store; the same holds for transposed convs with phase-major rows (ConvGemmArgs::pm); with channel-major rows
 // (channel, phase) pairs the bf16 values go out one by one.
-template <int BN, bool ENC = false>
+// Epilogue of one 32-row tile with octet-interleaved rows (pm == 2; the decoder blocks' transposed convs: bias, optional SnakeBeta
+// to y / y2 / the packed tensor -- no residual, scale or activation, which the host checks).
+template <int BN>
+__device__ __forceinline__ void tconv_oi_epilogue_tile(const ConvGemmArgs &a, const f32x16 &acc, const float *Pm, int n0, int rbase, int m,
+                                                       float *yu, float *y2u, unsigned short *ybu) {
+    const int S = a.S, h = (rbase >> 2) & 1, nb = n0 + (rbase & ~31);
+    const int sup = nb / (8 * S), ti = (nb - sup * 8 * S) >> 5;
+    const int c0 = 8 * sup, ph0 = (S >> 1) * h + 2 * ti;
+    if (c0 >= a.N / S || m >= a.M) return;                      // (rows are whole groups of 8 channels: N % (8 S) == 0)
+    float v[16], w[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int row = rbase + (r & 3) + 8 * (r >> 2);
+        v[r] = a.bias ? acc[r] + Pm[0 * BN + row] : acc[r];
+        w[r] = v[r];
+    }
+    if (a.psn_a) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {                       // registers r, r + 1: one channel, two phases
+            const int row = rbase + (r & 3) + 8 * (r >> 2);
+            const f32x2 sv = snake_beta2(mk2(v[r], v[r + 1]), mk2(Pm[2 * BN + row], Pm[2 * BN + row + 1]), mk2(Pm[3 * BN + row], Pm[3 * BN + row + 1]));
+            w[r] = sv.x; w[r + 1] = sv.y;
+        }
+    }
+    const long pos = (long)m * S + ph0;                          // even: 8-byte aligned in rows of 4 k floats
+    if (ybu) {
+        if (yu) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) *reinterpret_cast<float2 *>(yu + (long)(c0 + j) * a.y_cs + pos) = make_float2(v[2 * j], v[2 * j + 1]);
+        }
+        uint4 *e = reinterpret_cast<uint4 *>(ybu + (((long)(c0 >> 3) * a.y_cs + pos) << 3));
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const uint2 lo = pack4_bf16(w[p], w[2 + p], w[4 + p], w[6 + p]), hi = pack4_bf16(w[8 + p], w[10 + p], w[12 + p], w[14 + p]);
+            e[p] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+        return;
+    }
+    if (a.psn_a && y2u) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            *reinterpret_cast<float2 *>(yu + (long)(c0 + j) * a.y_cs + pos) = make_float2(v[2 * j], v[2 * j + 1]);
+            *reinterpret_cast<float2 *>(y2u + (long)(c0 + j) * a.y_cs + pos) = make_float2(w[2 * j], w[2 * j + 1]);
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) *reinterpret_cast<float2 *>(yu + (long)(c0 + j) * a.y_cs + pos) = make_float2(w[2 * j], w[2 * j + 1]);
+}
+
+// OI: the kernel instance for octet-interleaved transposed convs (pm == 2).  A compile-time choice: as a run-time branch the second
+// epilogue cost the 128-register bf16 kernels spills in every layer (measured: conv7 layers 8x slower).
+template <int BN, bool ENC = false, bool OI = false>
 __device__ __forceinline__ void conv_epilogue_tile(const ConvGemmArgs &a, const f32x16 &acc, const float *Pm, int n0, int rbase,
                                                    int m, float *yu, const float *ru, float *y2u, unsigned short *ybu = nullptr) {
+    if constexpr (OI) {
+        tconv_oi_epilogue_tile<BN>(a, acc, Pm, n0, rbase, m, yu, y2u, ybu);
+        return;
+    }
 #pragma unroll
     for (int half = 0; half < 2; half++) {
         long o[8];

@@ -125,6 +125,7 @@ struct Ctx {
     bool post_snake = true;
     bool fin_post = true;         // the final SnakeBeta in the last residual unit's epilogue (HIPVOC_FIN_POST)
     bool phase_major = true;   // transposed-conv rows phase-major (HIPVOC_PHASE_MAJOR=0: channel-major)
+    bool tconv_oi = true;      // ... octet-interleaved at stride 4 / 8 in the bf16 modes (HIPVOC_TCONV_OI=0: phase-major there too)
     bool packed = true;        // bf16 mode: GEMM-to-GEMM tensors of the decoder stack exchanged as packed bf16 (HIPVOC_PACKED=0: fp32)
     bool wino_tconv = true;    // fp32 mode: the decoder blocks' transposed convs by F(3,2) (HIPVOC_WINO_TCONV=0: direct)
     bool wino_unfuse = true;   // blocks whose residual units could be fused run un-fused when their conv7 has a Winograd form (HIPVOC_WINO_UNFUSE=0)
@@ -473,12 +474,15 @@ struct Loader {
         // fp32 with the Winograd trans-conv kernel: channel-major rows, so that one workgroup writes every phase of its
         // channels (whole cache lines leave the workgroup, not one phase's every s-th float)
         if (c->wino && c->wino_tconv && !c->bf16) g.pm = 0;
+        // bf16 / bf16x3 modes, stride 4 or 8: octet-interleaved rows (device_common.h: tconv_oi_row) -- a lane's registers are two
+        // adjacent phases of eight channels: whole cache lines leave the wave in both output tensors (HIPVOC_TCONV_OI=0: phase-major)
+        if (c->bf16 && c->tconv_oi && g.pm && (s == 4 || s == 8) && K == 2 * s) g.pm = 2;
         int CinP = rup(Cin, 32);
         std::vector<float> p((size_t)g.ntaps * CinP * g.NP, 0.0f);
         for (int ci = 0; ci < Cin; ci++)
             for (int co = 0; co < Co; co++)
                 for (int r = 0; r < s; r++) {
-                    const int n = g.pm ? r * Co + co : co * s + r;
+                    const int n = g.pm == 2 ? tconv_oi_n(co, r, s) : g.pm ? r * Co + co : co * s + r;
                     if (K == s) {
                         p[((size_t)ci) * g.NP + n] = w[((size_t)ci * Co + co) * K + r];
                     } else {
@@ -1437,6 +1441,7 @@ static void *load_impl(const char *weights_path, int device_id, int dtype, int u
     if (const char *ps = getenv("HIPVOC_DUAL")) c->dual_out = atoi(ps);
     if (const char *ps = getenv("HIPVOC_PACKED")) c->packed = atoi(ps) != 0;
     if (const char *ps = getenv("HIPVOC_PHASE_MAJOR")) c->phase_major = atoi(ps) != 0;
+    if (const char *ps = getenv("HIPVOC_TCONV_OI")) c->tconv_oi = atoi(ps) != 0;
     if (const char *ps = getenv("HIPVOC_WINO")) c->wino = atoi(ps) != 0;
     if (const char *ps = getenv("HIPVOC_WINO_UNFUSE")) c->wino_unfuse = atoi(ps) != 0;
     if (const char *ps = getenv("HIPVOC_WINO_TCONV")) c->wino_tconv = atoi(ps) != 0;

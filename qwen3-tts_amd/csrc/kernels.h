@@ -60,7 +60,8 @@ struct ConvGemmArgs {
     int Cin, N, NP, TN;
     int ntaps, shift0, shift_step;   // shift(tap) = shift0 + tap*shift_step
     int S;                           // out channel = n / S, out position = m*S + n % S
-    int pm;                          // S > 1, phase-major rows instead: out channel = n % (N/S), phase = n / (N/S); needs (N/S) % 8 == 0
+    int pm;                          // S > 1, 1: phase-major rows instead: out channel = n % (N/S), phase = n / (N/S); needs (N/S) % 8 == 0
+                                     // 2 (S = 4 or 8, (N/S) % 8 == 0): octet-interleaved rows -- see tconv_oi_row() in device_common.h
     int units;                       // G (1 in flat mode)
     int M;                           // GEMM columns per unit
     int Lin;                         // valid input positions per unit
@@ -92,6 +93,12 @@ const char *conv_gemm_bf16_kernel_name(const ConvGemmArgs &a);
 bool wino_selected(const ConvGemmArgs &a);            // kernels_wino.hip: F(2,7) Winograd form of the fp32 k = 7 convs
 hipError_t launch_wino_conv7(const ConvGemmArgs &a, hipStream_t s);
 const char *wino_kernel_name(const ConvGemmArgs &a);
+// Octet-interleaved row order of a transposed conv (ConvGemmArgs::pm == 2; device_common.h: tconv_oi_row is the inverse):
+// row of (channel c, phase ph) at stride S = 4 or 8.
+inline int tconv_oi_n(int c, int ph, int S) {
+    const int sup = c >> 3, j = c & 7, h = ph / (S >> 1), rem = ph - h * (S >> 1), ti = rem >> 1, r = 2 * j + (rem & 1);
+    return sup * 8 * S + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+}
 bool gemmd_selected(const ConvGemmArgs &a);           // kernels_wino.hip: large 1-tap GEMMs with both operands staged by LDS-DMA
 hipError_t launch_gemmd(const ConvGemmArgs &a, hipStream_t s);
 const char *gemmd_kernel_name(const ConvGemmArgs &a);

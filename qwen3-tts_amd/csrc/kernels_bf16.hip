@@ -45,7 +45,7 @@ __device__ __forceinline__ bf16x8 pack8(const f32x8 &v) {
 // mid = bf16(v - hi) (16 mantissa bits together), and a product is three MFMAs: hi*hi + hi*mid + mid*hi (the dropped
 // mid*mid term is 2^-16 of the product).  fp32-grade results at a third of the bf16 MFMA rate -- still several
 // times the fp32 MFMA rate.  Weights are split once at load (ConvGemmArgs::wbm / wb2m), activations at commit.
-template <int TN, bool FUSE, bool XB, bool X3>
+template <int TN, bool FUSE, bool XB, bool X3, bool OI = false>
 __device__ __forceinline__ void conv_gemm_bf16_body(const ConvGemmArgs &a, int HL, int XW, int tiles_per_unit, int n_tiles) {
     constexpr int BN = TN * 32;
     constexpr int WF = 4 * BN;                        // 16-byte elements per W tile [4 k-groups][BN rows]
@@ -403,7 +403,7 @@ __device__ __forceinline__ void conv_gemm_bf16_body(const ConvGemmArgs &a, int H
     unsigned short *ybu0 = launder_after(a.yb, acc[TN - 1][15]);
     unsigned short *ybu = ybu0 ? ybu0 + (((long)unit * a.y_us) << 3) : nullptr;
 #pragma unroll
-    for (int i = 0; i < TN; i++) conv_epilogue_tile<BN>(a, acc[i], Pm, n0, i * 32 + 4 * h, m, yu, ru, y2u, ybu);
+    for (int i = 0; i < TN; i++) conv_epilogue_tile<BN, false, OI>(a, acc[i], Pm, n0, i * 32 + 4 * h, m, yu, ru, y2u, ybu);
 }
 
 template <int TN, bool FUSE, bool XB>
@@ -416,6 +416,16 @@ template <int TN, bool FUSE>
 __global__ __launch_bounds__(NTHB, 2) void conv_gemm_bf16x3_kernel(ConvGemmArgs a, int HL, int XW, int tiles_per_unit,
                                                                    int n_tiles) {
     conv_gemm_bf16_body<TN, FUSE, false, true>(a, HL, XW, tiles_per_unit, n_tiles);
+}
+
+// the transposed convs with octet-interleaved rows (ConvGemmArgs::pm == 2; device_common.h: tconv_oi_epilogue_tile)
+template <int TN, bool XB>
+__global__ __launch_bounds__(NTHB, 4) void conv_gemm_bf16_oi_kernel(ConvGemmArgs a, int HL, int XW, int tiles_per_unit, int n_tiles) {
+    conv_gemm_bf16_body<TN, false, XB, false, true>(a, HL, XW, tiles_per_unit, n_tiles);
+}
+template <int TN>
+__global__ __launch_bounds__(NTHB, 2) void conv_gemm_bf16x3_oi_kernel(ConvGemmArgs a, int HL, int XW, int tiles_per_unit, int n_tiles) {
+    conv_gemm_bf16_body<TN, false, false, true, true>(a, HL, XW, tiles_per_unit, n_tiles);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -437,6 +447,15 @@ const char *conv_gemm_bf16_kernel_name(const ConvGemmArgs &a) {
     static char names[2][2][8][56];
     int tn = detail::conv_gemm_launch_tn(a);
     int fuse = a.wb2 ? 1 : 0, xbf = a.xb ? 1 : 0;
+    if (a.S > 1 && a.pm == 2) {
+        static char no[3][8][48];
+        char *m = no[a.wbm ? 2 : xbf][tn & 7];
+        if (!m[0]) {
+            if (a.wbm) snprintf(m, 48, "conv_gemm_bf16x3_oi_kernel<%d>", tn);
+            else snprintf(m, 48, "conv_gemm_bf16_oi_kernel<%d,%s>", tn, xbf ? "true" : "false");
+        }
+        return m;
+    }
     char *n = names[fuse][xbf][tn & 7];
     if (a.wbm) {
         static char n3[2][8][48];
@@ -463,6 +482,22 @@ static hipError_t launch_one_bf16(const ConvGemmArgs &a, int HL, int XW, int til
     }
     hipLaunchKernelGGL((conv_gemm_bf16_kernel<TN, FUSE, XB>), dim3((unsigned)grid), dim3(NTHB), lds, s, a, HL, XW,
                        tiles_per_unit, n_tiles);
+    return hipGetLastError();
+}
+
+// (any kernel of this file's signature: the one-off raise of the dynamic LDS limit per device, then the launch)
+template <auto KERN>
+static hipError_t launch_fn_bf16(const ConvGemmArgs &a, int HL, int XW, int tiles_per_unit, int n_tiles, long grid, size_t lds, hipStream_t s) {
+    static bool done[64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64 && !done[dev]) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(KERN), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        done[dev] = true;
+    }
+    hipLaunchKernelGGL(KERN, dim3((unsigned)grid), dim3(NTHB), lds, s, a, HL, XW, tiles_per_unit, n_tiles);
     return hipGetLastError();
 }
 
@@ -506,6 +541,10 @@ hipError_t launch_conv_gemm_bf16(const ConvGemmArgs &a_in, hipStream_t s) {
     if (a.xb && ((a.Cin & 7) || a.sn_a || ((uintptr_t)a.xb & 15) || (long)a.x_cs * 16 * 5 >= 0x7fffffffL)) return hipErrorInvalidValue;
     if (a.yb && (((a.N / a.S) & 7) || (a.N % a.S) || ((uintptr_t)a.yb & 15))) return hipErrorInvalidValue;
     if (!a.y && !a.yb) return hipErrorInvalidValue;
+    // octet-interleaved transposed-conv rows (device_common.h: tconv_oi_epilogue_tile): what that epilogue assumes
+    if (a.S > 1 && a.pm == 2 && ((a.S != 4 && a.S != 8) || a.N % (8 * a.S) || a.res || a.rscale || a.act != ACT_NONE || (a.y_cs & 1) || (a.y_us & 1) ||
+                                 (a.y && ((uintptr_t)a.y & 7)) || (a.y2 && ((uintptr_t)a.y2 & 7)) || (!a.y && !a.yb)))
+        return hipErrorInvalidValue;
     if (a.wb2 && (a.S != 1 || a.NP != 32 * tn || (a.N + 31) / 32 != tn || tn == 5 || tn > 6 || !a.res || !a.sn2_a ||
                   !a.sn2_ib || !a.bias || !a.bias2 || ((uintptr_t)a.wb2 & 15)))
         return hipErrorInvalidValue;
@@ -515,6 +554,25 @@ hipError_t launch_conv_gemm_bf16(const ConvGemmArgs &a_in, hipStream_t s) {
     if (grid > 0x7fffffffL) return hipErrorInvalidValue;
     size_t lds = conv_gemm_bf16_lds_bytes(a);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
+    if (a.S > 1 && a.pm == 2) {     // octet-interleaved transposed conv: its own kernel instances (never fused)
+        if (a.wb2 || (tn != 1 && tn != 2 && tn != 4)) return hipErrorInvalidValue;
+#define GOI(K_) return launch_fn_bf16<K_>(a, HL, XW, tiles_per_unit, n_tiles, grid, lds, s)
+        if (a.wbm) {
+            if (a.xb || a.yb || ((uintptr_t)a.wbm & 15)) return hipErrorInvalidValue;
+            if (tn == 1) GOI(conv_gemm_bf16x3_oi_kernel<1>);
+            if (tn == 2) GOI(conv_gemm_bf16x3_oi_kernel<2>);
+            GOI(conv_gemm_bf16x3_oi_kernel<4>);
+        }
+        if (a.xb) {
+            if (tn == 1) GOI((conv_gemm_bf16_oi_kernel<1, true>));
+            if (tn == 2) GOI((conv_gemm_bf16_oi_kernel<2, true>));
+            GOI((conv_gemm_bf16_oi_kernel<4, true>));
+        }
+        if (tn == 1) GOI((conv_gemm_bf16_oi_kernel<1, false>));
+        if (tn == 2) GOI((conv_gemm_bf16_oi_kernel<2, false>));
+        GOI((conv_gemm_bf16_oi_kernel<4, false>));
+#undef GOI
+    }
 #define GOX(TN_, F_, X_) return launch_one_bf16<TN_, F_, X_>(a, HL, XW, tiles_per_unit, n_tiles, grid, lds, s)
 #define SW(F_, X_)                  \
     switch (tn) {                   \

@@ -85,6 +85,10 @@ typedef const volatile __attribute__((address_space(3))) float *wn_vlds_t;
 #ifndef GEMMD_NW_DEFAULT
 #define GEMMD_NW_DEFAULT 4
 #endif
+#ifndef WN_PS_OCC
+#define WN_PS_OCC 3          // workgroups per CU the 4-wave conv7 form is compiled for: 3 = at most 168 registers per lane (hipcc needs 171
+                             // at 2: five dwords of scratch outside the loop) and 42-48 KB of LDS each; conv7 layers 2-5 % faster than at 2
+#endif
 #ifndef WN_DG
 #define WN_DG 2
 #endif
@@ -424,7 +428,7 @@ struct PsGeom {
 };
 
 template <int D, int RT, bool FUSE, int NTG, int BK>
-__global__ __launch_bounds__((PsGeom<D, RT, NTG, BK>::NTH), (NTG == 2 ? 2 : 1)) void wino_ps_kernel(ConvGemmArgs a, int wg_per_unit, int n_tiles) {
+__global__ __launch_bounds__((PsGeom<D, RT, NTG, BK>::NTH), (NTG == 2 ? (FUSE ? 2 : WN_PS_OCC) : 1)) void wino_ps_kernel(ConvGemmArgs a, int wg_per_unit, int n_tiles) {
     using GEO = PsGeom<D, RT, NTG, BK>;
     constexpr int NTH = GEO::NTH, BN = GEO::BN, XW = GEO::XW, XP = GEO::XP, XBUF = GEO::XBUF, WP = GEO::WP, WBUF = GEO::WBUF, xw4 = XW / 4;
     constexpr int PMF = FUSE ? 6 : 4;
