@@ -109,6 +109,7 @@ __device__ __forceinline__ void fill_param_table(const ConvGemmArgs &a, float *P
         const int n = n0 + row;
         int co = a.S > 1 ? (a.pm ? n % (a.N / a.S) : n / a.S) : n;
         if (a.S > 1 && a.pm == 2) { int ph_; tconv_oi_row(n, a.S, co, ph_); }
+        if (a.S > 1 && a.pm == 3) { const int t = n % (32 * a.S); co = (n / (32 * a.S)) * 32 + (t & 31); }      // phase-tile rows, see tconv_pt_epilogue
         if constexpr (FUSE) {
             Pm[0 * BN + row] = a.bias[co];
             Pm[1 * BN + row] = a.sn2_a[co];
@@ -186,6 +187,62 @@ __device__ __forceinline__ void tconv_oi_epilogue_tile(const ConvGemmArgs &a, co
     }
 #pragma unroll
     for (int j = 0; j < 8; j++) *reinterpret_cast<float2 *>(yu + (long)(c0 + j) * a.y_cs + pos) = make_float2(w[2 * j], w[2 * j + 1]);
+}
+
+// Phase-tile rows (ConvGemmArgs::pm == 3; odd strides S = 3, 5; Cout % 32 == 0): the workgroup's S row tiles are the S phases of
+// the same 32 channels (row n = (c / 32) 32 S + phase 32 + c % 32), so the lane that holds channel c at input step m in tile 0
+// holds its other phases in the same register of the other tiles: S consecutive floats of y (4-byte stores that tile whole lines
+// across the wave and the S store instructions), and for the packed tensor the 8-byte halves (four channels) of S adjacent
+// elements.  Needs the launch's tile height to be S (detail::conv_gemm_launch_tn).
+template <int BN, int S>
+__device__ __forceinline__ void tconv_pt_epilogue(const ConvGemmArgs &a, const f32x16 (&acc)[S], const float *Pm, int n0, int h, int m,
+                                                  float *yu, float *y2u, unsigned short *ybu) {
+    static_assert(BN == 32 * S, "one row tile per phase");
+    const int cbase = (n0 / BN) * 32;
+    if (m >= a.M) return;
+    const long pos = (long)m * S;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {                               // registers 4g .. 4g+3: channels c .. c+3
+        const int c = cbase + 8 * g + 4 * h;
+        if (c >= a.N / S) continue;
+        float v[S][4], w[S][4];
+#pragma unroll
+        for (int ph = 0; ph < S; ph++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int row = ph * 32 + 8 * g + 4 * h + j;
+                v[ph][j] = a.bias ? acc[ph][4 * g + j] + Pm[0 * BN + row] : acc[ph][4 * g + j];
+                w[ph][j] = v[ph][j];
+            }
+        if (a.psn_a) {
+#pragma unroll
+            for (int ph = 0; ph < S; ph++)
+#pragma unroll
+                for (int j = 0; j < 4; j += 2) {
+                    const int row = ph * 32 + 8 * g + 4 * h + j;
+                    const f32x2 sv = snake_beta2(mk2(v[ph][j], v[ph][j + 1]), mk2(Pm[2 * BN + row], Pm[2 * BN + row + 1]), mk2(Pm[3 * BN + row], Pm[3 * BN + row + 1]));
+                    w[ph][j] = sv.x; w[ph][j + 1] = sv.y;
+                }
+        }
+        const bool raw_y = ybu || (a.psn_a && y2u);             // y keeps the raw value when the activated one has its own tensor
+        if (yu) {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int ph = 0; ph < S; ph++) yu[(long)(c + j) * a.y_cs + pos + ph] = raw_y ? v[ph][j] : w[ph][j];
+        }
+        if (!ybu && a.psn_a && y2u) {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int ph = 0; ph < S; ph++) y2u[(long)(c + j) * a.y_cs + pos + ph] = w[ph][j];
+        }
+        if (ybu) {
+#pragma unroll
+            for (int ph = 0; ph < S; ph++)
+                *reinterpret_cast<uint2 *>(ybu + ((((long)(c >> 3) * a.y_cs + pos + ph) << 3) + (c & 4))) = pack4_bf16(w[ph][0], w[ph][1], w[ph][2], w[ph][3]);
+        }
+    }
 }
 
 // OI: the kernel instance for octet-interleaved transposed convs (pm == 2).  A compile-time choice: as a run-time branch the second

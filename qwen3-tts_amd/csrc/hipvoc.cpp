@@ -477,12 +477,18 @@ struct Loader {
         // bf16 / bf16x3 modes, stride 4 or 8: octet-interleaved rows (device_common.h: tconv_oi_row) -- a lane's registers are two
         // adjacent phases of eight channels: whole cache lines leave the wave in both output tensors (HIPVOC_TCONV_OI=0: phase-major)
         if (c->bf16 && c->tconv_oi && g.pm && (s == 4 || s == 8) && K == 2 * s) g.pm = 2;
+        // ... strides 3 and 5: phase-tile rows (tconv_pt_epilogue): the S row tiles of a workgroup are the S phases of 32 channels
+        if (c->bf16 && c->tconv_oi && g.pm == 1 && (s == 3 || s == 5) && K == 2 * s && Co % 32 == 0) {
+            g.pm = 3;
+            g.TN = s;
+            g.NP = rup(g.N, 32 * g.TN);
+        }
         int CinP = rup(Cin, 32);
         std::vector<float> p((size_t)g.ntaps * CinP * g.NP, 0.0f);
         for (int ci = 0; ci < Cin; ci++)
             for (int co = 0; co < Co; co++)
                 for (int r = 0; r < s; r++) {
-                    const int n = g.pm == 2 ? tconv_oi_n(co, r, s) : g.pm ? r * Co + co : co * s + r;
+                    const int n = g.pm == 3 ? (co / 32) * 32 * s + r * 32 + co % 32 : g.pm == 2 ? tconv_oi_n(co, r, s) : g.pm ? r * Co + co : co * s + r;
                     if (K == s) {
                         p[((size_t)ci) * g.NP + n] = w[((size_t)ci * Co + co) * K + r];
                     } else {

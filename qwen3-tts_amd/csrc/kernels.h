@@ -62,6 +62,7 @@ struct ConvGemmArgs {
     int S;                           // out channel = n / S, out position = m*S + n % S
     int pm;                          // S > 1, 1: phase-major rows instead: out channel = n % (N/S), phase = n / (N/S); needs (N/S) % 8 == 0
                                      // 2 (S = 4 or 8, (N/S) % 8 == 0): octet-interleaved rows -- see tconv_oi_row() in device_common.h
+                                     // 3 (S = 3 or 5, (N/S) % 32 == 0, TN = S): phase-tile rows -- see tconv_pt_epilogue() there
     int units;                       // G (1 in flat mode)
     int M;                           // GEMM columns per unit
     int Lin;                         // valid input positions per unit

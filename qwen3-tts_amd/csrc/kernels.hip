@@ -361,6 +361,7 @@ void detail::conv_gemm_geometry(const ConvGemmArgs &a, int &HL, int &XW, int bm)
 // NP/32 for the fused residual unit (one tile must hold every channel).
 int detail::conv_gemm_launch_tn(const ConvGemmArgs &a) {
     if (a.w2 || a.wb2) return a.NP / 32;
+    if (a.S > 1 && a.pm == 3) return a.S;               // phase-tile rows of a transposed conv: one row tile per phase
     int tiles_m = ((a.M + BM - 1) / BM) * a.units;
     int tn = a.TN;
     static int min_wgs = -1;
@@ -444,7 +445,7 @@ hipError_t launch_conv_gemm(const ConvGemmArgs &a_in, hipStream_t s) {
         return hipErrorInvalidValue;
     const int tn = conv_gemm_launch_tn(a);
     if (a.y2 && (!a.psn_a || !a.psn_ib || a.w2)) return hipErrorInvalidValue;
-    if (a.pm == 2) return hipErrorInvalidValue;      // (octet-interleaved trans-conv rows: bf16-mode kernels only)
+    if (a.pm >= 2) return hipErrorInvalidValue;      // (octet-interleaved / phase-tile trans-conv rows: bf16-mode kernels only)
     if ((a.in_elu || a.act == ACT_ELU || a.act == ACT_GELU_TANH || a.s2d > 1) && (a.w2 || a.sn_a)) return hipErrorInvalidValue;
     if (a.s2d > 1 && (a.S != 1 || a.M % a.s2d || a.y2 || a.psn_a || a.units < 1)) return hipErrorInvalidValue;
     if (a.w2 && (a.S != 1 || a.NP != 32 * tn || (a.N + 31) / 32 != tn || tn == 5 || tn > 6 || !a.res || !a.sn2_a ||

@@ -45,7 +45,7 @@ __device__ __forceinline__ bf16x8 pack8(const f32x8 &v) {
 // mid = bf16(v - hi) (16 mantissa bits together), and a product is three MFMAs: hi*hi + hi*mid + mid*hi (the dropped
 // mid*mid term is 2^-16 of the product).  fp32-grade results at a third of the bf16 MFMA rate -- still several
 // times the fp32 MFMA rate.  Weights are split once at load (ConvGemmArgs::wbm / wb2m), activations at commit.
-template <int TN, bool FUSE, bool XB, bool X3, bool OI = false>
+template <int TN, bool FUSE, bool XB, bool X3, int OI = 0>      // OI: 0, or ConvGemmArgs::pm of a transposed conv with its own epilogue (2, 3)
 __device__ __forceinline__ void conv_gemm_bf16_body(const ConvGemmArgs &a, int HL, int XW, int tiles_per_unit, int n_tiles) {
     constexpr int BN = TN * 32;
     constexpr int WF = 4 * BN;                        // 16-byte elements per W tile [4 k-groups][BN rows]
@@ -402,8 +402,12 @@ __device__ __forceinline__ void conv_gemm_bf16_body(const ConvGemmArgs &a, int H
     const int m = m0 + wave * 32 + l31;
     unsigned short *ybu0 = launder_after(a.yb, acc[TN - 1][15]);
     unsigned short *ybu = ybu0 ? ybu0 + (((long)unit * a.y_us) << 3) : nullptr;
+    if constexpr (OI == 3) {
+        tconv_pt_epilogue<BN, TN>(a, acc, Pm, n0, h, m, yu, y2u, ybu);
+        return;
+    }
 #pragma unroll
-    for (int i = 0; i < TN; i++) conv_epilogue_tile<BN, false, OI>(a, acc[i], Pm, n0, i * 32 + 4 * h, m, yu, ru, y2u, ybu);
+    for (int i = 0; i < TN; i++) conv_epilogue_tile<BN, false, OI == 2>(a, acc[i], Pm, n0, i * 32 + 4 * h, m, yu, ru, y2u, ybu);
 }
 
 template <int TN, bool FUSE, bool XB>
@@ -421,11 +425,21 @@ __global__ __launch_bounds__(NTHB, 2) void conv_gemm_bf16x3_kernel(ConvGemmArgs 
 // the transposed convs with octet-interleaved rows (ConvGemmArgs::pm == 2; device_common.h: tconv_oi_epilogue_tile)
 template <int TN, bool XB>
 __global__ __launch_bounds__(NTHB, 4) void conv_gemm_bf16_oi_kernel(ConvGemmArgs a, int HL, int XW, int tiles_per_unit, int n_tiles) {
-    conv_gemm_bf16_body<TN, false, XB, false, true>(a, HL, XW, tiles_per_unit, n_tiles);
+    conv_gemm_bf16_body<TN, false, XB, false, 2>(a, HL, XW, tiles_per_unit, n_tiles);
 }
 template <int TN>
 __global__ __launch_bounds__(NTHB, 2) void conv_gemm_bf16x3_oi_kernel(ConvGemmArgs a, int HL, int XW, int tiles_per_unit, int n_tiles) {
-    conv_gemm_bf16_body<TN, false, false, true, true>(a, HL, XW, tiles_per_unit, n_tiles);
+    conv_gemm_bf16_body<TN, false, false, true, 2>(a, HL, XW, tiles_per_unit, n_tiles);
+}
+
+// ... and with phase-tile rows (pm == 3: strides 3 and 5; TN = stride; device_common.h: tconv_pt_epilogue)
+template <int TN, bool XB>
+__global__ __launch_bounds__(NTHB, (TN > 4) ? 2 : 4) void conv_gemm_bf16_pt_kernel(ConvGemmArgs a, int HL, int XW, int tiles_per_unit, int n_tiles) {
+    conv_gemm_bf16_body<TN, false, XB, false, 3>(a, HL, XW, tiles_per_unit, n_tiles);
+}
+template <int TN>
+__global__ __launch_bounds__(NTHB, 2) void conv_gemm_bf16x3_pt_kernel(ConvGemmArgs a, int HL, int XW, int tiles_per_unit, int n_tiles) {
+    conv_gemm_bf16_body<TN, false, false, true, 3>(a, HL, XW, tiles_per_unit, n_tiles);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -447,6 +461,15 @@ const char *conv_gemm_bf16_kernel_name(const ConvGemmArgs &a) {
     static char names[2][2][8][56];
     int tn = detail::conv_gemm_launch_tn(a);
     int fuse = a.wb2 ? 1 : 0, xbf = a.xb ? 1 : 0;
+    if (a.S > 1 && a.pm == 3) {
+        static char np[3][8][48];
+        char *m = np[a.wbm ? 2 : xbf][tn & 7];
+        if (!m[0]) {
+            if (a.wbm) snprintf(m, 48, "conv_gemm_bf16x3_pt_kernel<%d>", tn);
+            else snprintf(m, 48, "conv_gemm_bf16_pt_kernel<%d,%s>", tn, xbf ? "true" : "false");
+        }
+        return m;
+    }
     if (a.S > 1 && a.pm == 2) {
         static char no[3][8][48];
         char *m = no[a.wbm ? 2 : xbf][tn & 7];
@@ -532,7 +555,7 @@ hipError_t launch_conv_gemm_bf16(const ConvGemmArgs &a_in, hipStream_t s) {
     detail::conv_gemm_geometry(a, HL, XW);
     if (a.M <= 0 || a.units <= 0) return hipSuccess;
     // host-side shape checks: what the kernel's staging loops and vector accesses assume
-    if (!a.wb || (a.NP % (32 * a.TN)) || a.NP < a.N || a.TN < 1 || a.TN > 4 || ((uintptr_t)a.wb & 15) || a.ntaps < 1 ||
+    if (!a.wb || (a.NP % (32 * a.TN)) || a.NP < a.N || a.TN < 1 || (a.TN > 4 && !(a.pm == 3 && a.TN == 5)) || ((uintptr_t)a.wb & 15) || a.ntaps < 1 ||
         a.S < 1 || 4 * XW > 3 * NTHB ||
         (long)a.x_cs * 4 * (BKB + 1) >= 0x7fffffffL)   // 32-bit byte offsets of the buffer loads (a channel block + a row)
         return hipErrorInvalidValue;
@@ -554,6 +577,23 @@ hipError_t launch_conv_gemm_bf16(const ConvGemmArgs &a_in, hipStream_t s) {
     if (grid > 0x7fffffffL) return hipErrorInvalidValue;
     size_t lds = conv_gemm_bf16_lds_bytes(a);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
+    if (a.S > 1 && a.pm == 3) {     // phase-tile rows: tile height = stride
+        if (a.wb2 || tn != a.S || (tn != 3 && tn != 5) || (a.N / a.S) % 32 || a.N % a.S || a.NP != a.N || a.res || a.rscale || a.act != ACT_NONE)
+            return hipErrorInvalidValue;
+#define GPT(K_) return launch_fn_bf16<K_>(a, HL, XW, tiles_per_unit, n_tiles, grid, lds, s)
+        if (a.wbm) {
+            if (a.xb || a.yb || ((uintptr_t)a.wbm & 15)) return hipErrorInvalidValue;
+            if (tn == 3) GPT(conv_gemm_bf16x3_pt_kernel<3>);
+            GPT(conv_gemm_bf16x3_pt_kernel<5>);
+        }
+        if (a.xb) {
+            if (tn == 3) GPT((conv_gemm_bf16_pt_kernel<3, true>));
+            GPT((conv_gemm_bf16_pt_kernel<5, true>));
+        }
+        if (tn == 3) GPT((conv_gemm_bf16_pt_kernel<3, false>));
+        GPT((conv_gemm_bf16_pt_kernel<5, false>));
+#undef GPT
+    }
     if (a.S > 1 && a.pm == 2) {     // octet-interleaved transposed conv: its own kernel instances (never fused)
         if (a.wb2 || (tn != 1 && tn != 2 && tn != 4)) return hipErrorInvalidValue;
 #define GOI(K_) return launch_fn_bf16<K_>(a, HL, XW, tiles_per_unit, n_tiles, grid, lds, s)
