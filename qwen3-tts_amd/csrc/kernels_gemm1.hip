@@ -178,6 +178,10 @@ bool gemm1_selected(const ConvGemmArgs &a) {
     const char *e = getenv("HIPVOC_GEMM1_WGS");      // read per call: a test toggles it between two handles
     const int max_wgs = e ? atoi(e) : 384;
     if (max_wgs <= 0 || !g1_supported(a)) return false;
+    // layers the LDS-DMA kernels take (activated input, Cin % 16 == 0, stride 1) are theirs at every size: gemm_dmas_kernel on small
+    // launches, gemm_dma_kernel above (the transformer's projections at 64 units: 15-35 % faster there than here).  HIPVOC_GEMM1_DMA=1
+    // keeps them here.
+    if (gemmd_selected(a) && !getenv("HIPVOC_GEMM1_DMA")) return false;
     const long tiles_m = (long)((a.M + 255) / 256) * a.units;
     return tiles_m * (a.NP / (32 * detail::conv_gemm_launch_tn(a))) <= max_wgs;
 }
