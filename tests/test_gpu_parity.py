@@ -427,3 +427,55 @@ def test_gemm_dma_bitwise(pkg, synth, monkeypatch):
         assert np.array_equal(np.asarray(x).view(np.uint32), np.asarray(y).view(np.uint32))
     assert np.array_equal(outs["1"][1].view(np.uint32), outs["0"][1].view(np.uint32))
     assert np.array_equal(np.asarray(outs["1"][0][0]).view(np.uint32), outs["1"][1].view(np.uint32))      # batch == single
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [0, 1, 2])
+def test_layout_and_placement_switches_do_not_change_a_bit(pkg, synth, monkeypatch, dtype):
+    """Choices that move work between kernels or permute rows without touching any output element's arithmetic must leave the
+    waveform bit-identical, in every dtype mode, for a 10 s utterance (small launches) and a 6-utterance batch:
+      HIPVOC_FIN_POST=0          the final SnakeBeta inside final_conv_kernel instead of the last residual unit's epilogue;
+      HIPVOC_TCONV_OI=0          bf16 / bf16x3: phase-major rows instead of the octet-interleaved / phase-tile orders (their own
+                                 kernel instances -- which must really have run);
+      HIPVOC_WINO_TCONV_SMALL=0  fp32: the trans-convs' large-launch workgroup shapes on a small launch too;
+      HIPVOC_GEMMDS_NW=1, HIPVOC_GEMM1_DMA=1   fp32: one-wave workgroups of gemm_dmas_kernel; gemm1_kernel for the layers the
+                                 LDS-DMA kernels otherwise take."""
+    cfg = synth.FULL
+    voc_for(pkg, synth, "FULL", 0, 64)                         # makes the checkpoint file
+    path = os.path.join(tempfile.gettempdir(), "hipvoc_test_FULL_0.safetensors")
+    codes = [synth.make_codes(125, 4000 + i, cfg) for i in range(6)]
+
+    def run(env):
+        for k, val in env.items():
+            monkeypatch.setenv(k, val)
+        v = pkg.HipVocoder.load(path, device=0, unit_frames=64, dtype=dtype)
+        v.set_profile(True)
+        small = v.synthesize(codes[0])
+        names = {k.split("|")[1] for k in v.last_profile()}
+        big = v.synthesize_batch(codes) if hasattr(v, "synthesize_batch") else [v.synthesize(c) for c in codes]
+        names |= {k.split("|")[1] for k in v.last_profile()}
+        v.close()
+        for k in env:
+            monkeypatch.delenv(k)
+        return small, big, names
+
+    ref_small, ref_big, ref_names = run({})
+    if dtype == 0:
+        assert any(n.startswith("gemm_dmas_kernel<1,2,8>") for n in ref_names), ref_names
+        assert any(n.startswith("wino_tconv_kernel<false,1,2,") for n in ref_names), ref_names       # a 64-row small-launch shape
+    else:
+        assert any("_oi_kernel<" in n for n in ref_names) and any("_pt_kernel<" in n for n in ref_names), ref_names
+    switches = [{"HIPVOC_FIN_POST": "0"}]
+    switches += [{"HIPVOC_WINO_TCONV_SMALL": "0"}, {"HIPVOC_GEMMDS_NW": "1"}, {"HIPVOC_GEMM1_DMA": "1"}] if dtype == 0 else [{"HIPVOC_TCONV_OI": "0"}]
+    for env in switches:
+        small, big, names = run(env)
+        if "HIPVOC_TCONV_OI" in env:
+            assert not any("_oi_kernel<" in n or "_pt_kernel<" in n for n in names), names
+        if "HIPVOC_WINO_TCONV_SMALL" in env:
+            assert not any(n.startswith("wino_tconv_kernel<false,1,2,") for n in names), names
+        if "HIPVOC_GEMMDS_NW" in env:
+            assert any(n.startswith("gemm_dmas_kernel<1,1,8>") for n in names), names
+        assert np.array_equal(small.view(np.uint32), ref_small.view(np.uint32)), env
+        for x, y in zip(big, ref_big):
+            assert np.array_equal(np.asarray(x).view(np.uint32), np.asarray(y).view(np.uint32)), env
+    assert np.array_equal(np.asarray(ref_big[0]).view(np.uint32), ref_small.view(np.uint32))           # batch == single
