@@ -752,22 +752,22 @@ static constexpr int WT_PTS = 4;
 
 // NTG = tile groups of 32 tiles per workgroup: 4, or 3 (96 tiles: a unit of 85 tiles -- block 0's 256 input steps -- fills 89 % of
 // such a workgroup instead of 66 % of a 128-tile one)
-template <int RT, int RW, int NTG>
+template <int RT, int RW, int NTG, int BK = WN_BK>
 struct TconvGeom {
     static constexpr int NTH = NTG * RW * 64;
     static constexpr int NT = 32 * NTG;                                      // tiles per workgroup
     static constexpr int BN = 32 * RT * RW;                                  // rows per workgroup
     static constexpr int XW = 3 * NT + 8;                                    // window: positions 3 T0 + sh (floored to 4) .. + 3 NT + 3
-    static constexpr int XP = (WN_BK * (XW / 4) + NTH - 1) / NTH;
+    static constexpr int XP = (BK * (XW / 4) + NTH - 1) / NTH;
     static constexpr int XBUF = XP * NTH * 4;
-    static constexpr int WF4 = WT_PTS * WN_BK * BN / 4;                      // float4 of the weight tiles of one block
+    static constexpr int WF4 = WT_PTS * BK * BN / 4;                      // float4 of the weight tiles of one block
     static constexpr int WP = (WF4 + NTH - 1) / NTH;
     static constexpr int WBUF = WP * NTH * 4;
 };
 
-template <bool SN, int RT, int RW, int NTG>
-__global__ __launch_bounds__((TconvGeom<RT, RW, NTG>::NTH), 1) void wino_tconv_kernel(ConvGemmArgs a, int wg_per_unit, int n_tiles) {
-    using GEO = TconvGeom<RT, RW, NTG>;
+template <bool SN, int RT, int RW, int NTG, int BK = WN_BK>
+__global__ __launch_bounds__((TconvGeom<RT, RW, NTG, BK>::NTH), (BK == 8 ? 3 : 1)) void wino_tconv_kernel(ConvGemmArgs a, int wg_per_unit, int n_tiles) {
+    using GEO = TconvGeom<RT, RW, NTG, BK>;
     constexpr int NTH = GEO::NTH, BN = GEO::BN, XW = GEO::XW, XP = GEO::XP, XBUF = GEO::XBUF, WP = GEO::WP, WBUF = GEO::WBUF, xw4 = XW / 4;
     extern __shared__ __attribute__((aligned(16))) float smem_all[];
     float *Pm = smem_all;                                   // [4][BN] per-row parameters: bias | - | psn_a | psn_ib
@@ -789,7 +789,7 @@ __global__ __launch_bounds__((TconvGeom<RT, RW, NTG>::NTH), 1) void wino_tconv_k
     const int tw = wave % NTG, rw = wave / NTG;             // tile group, wave-row
     const float *xu = a.x + (long)unit * a.x_us;
     const int CinP = ((a.Cin + 31) / 32) * 32;
-    const int ncb = a.Cin / WN_BK;
+    const int ncb = a.Cin / BK;
     const int sh = a.shift0;
 
     const int pwin0 = (3 * T0 + sh) & ~3;                   // first position of the window (floor to 4, also when negative)
@@ -818,7 +818,7 @@ __global__ __launch_bounds__((TconvGeom<RT, RW, NTG>::NTH), 1) void wino_tconv_k
         const int i = tid + NTH * j;
         int row = i / xw4;
         const int c4 = i - row * xw4;
-        row = row < WN_BK ? row : 0;                         // pieces past the window land in the buffer's padding
+        row = row < BK ? row : 0;                         // pieces past the window land in the buffer's padding
         int pos = pwin0 + 4 * c4;
         pos = pos < 0 ? 0 : (pos > xlim ? xlim : pos);
         xo[j] = (unsigned)row * (unsigned)a.x_cs + (unsigned)pos;
@@ -827,16 +827,16 @@ __global__ __launch_bounds__((TconvGeom<RT, RW, NTG>::NTH), 1) void wino_tconv_k
     for (int k = 0; k < WP; k++) {                           // float4 index tid + NTH k of the [4][16][BN] image
         int i = tid + NTH * k;
         i = i < GEO::WF4 ? i : 0;                            // (pieces past the image re-read its start into the padding)
-        const int q = i / (WN_BK * BN / 4), rem = i - q * (WN_BK * BN / 4), r = rem / (BN / 4), c4 = rem - r * (BN / 4);
+        const int q = i / (BK * BN / 4), rem = i - q * (BK * BN / 4), r = rem / (BN / 4), c4 = rem - r * (BN / 4);
         wo[k] = ((unsigned)q * (unsigned)CinP + (unsigned)r) * (unsigned)a.NP + (unsigned)c4 * 4u;
     }
     auto stage = [&](int cb, int buf) {
-        const float *xb = xu + (long)cb * WN_BK * a.x_cs;
+        const float *xb = xu + (long)cb * BK * a.x_cs;
         float *xd = Xs + buf * XBUF + wave * 256;
 #pragma unroll
         for (int j = 0; j < XP; j++)
             wn_dma16(xb + xo[j], xd + j * (NTH * 4));
-        const float *wb = a.ww + ((long)cb * WN_BK) * a.NP + n0;
+        const float *wb = a.ww + ((long)cb * BK) * a.NP + n0;
         float *wd = Ws + buf * WBUF + wave * 256;
 #pragma unroll
         for (int k = 0; k < WP; k++)
@@ -858,7 +858,7 @@ __global__ __launch_bounds__((TconvGeom<RT, RW, NTG>::NTH), 1) void wino_tconv_k
         {
             const float *xs = Xs + buf * XBUF + xoff;
             const float *ws = Ws + buf * WBUF + l31 + rw * (32 * RT);
-            const float *sp = Sp + 2 * (cb * WN_BK + h);
+            const float *sp = Sp + 2 * (cb * BK + h);
             float dv[3][4], vv[2][WT_PTS], av[2][WT_PTS][RT];
             float2 sv[3];
             auto load_d = [&](int kk, int sl) {
@@ -872,7 +872,7 @@ __global__ __launch_bounds__((TconvGeom<RT, RW, NTG>::NTH), 1) void wino_tconv_k
 #pragma unroll
                 for (int q = 0; q < WT_PTS; q++)
 #pragma unroll
-                    for (int i = 0; i < RT; i++) av[sl][q][i] = WN_LDS(wk + q * (WN_BK * BN) + 32 * i);
+                    for (int i = 0; i < RT; i++) av[sl][q][i] = WN_LDS(wk + q * (BK * BN) + 32 * i);
             };
             auto transform = [&](int ds, int vs) {
                 float d[4];
@@ -897,10 +897,10 @@ __global__ __launch_bounds__((TconvGeom<RT, RW, NTG>::NTH), 1) void wino_tconv_k
             load_d(1, 1);
             transform(0, 0);
 #pragma unroll
-            for (int kk = 0; kk < WN_BK / 2; kk++) {
+            for (int kk = 0; kk < BK / 2; kk++) {
                 __builtin_amdgcn_sched_barrier(0);
-                if (kk + 2 < WN_BK / 2) load_d(kk + 2, (kk + 2) % 3);
-                if (kk + 1 < WN_BK / 2) {
+                if (kk + 2 < BK / 2) load_d(kk + 2, (kk + 2) % 3);
+                if (kk + 1 < BK / 2) {
                     load_a(kk + 1, (kk + 1) & 1);
                     transform((kk + 1) % 3, (kk + 1) & 1);
                 }
@@ -1012,9 +1012,19 @@ static bool wino_tconv_tiles96(const ConvGemmArgs &a) {
 // cheapest of the instantiated shapes by rounds x work per SIMD: a grid of 128 12-wave workgroups leaves half the chip idle, one
 // of 324 runs two rounds for 1.3.  The 64-row shapes (RT 1, RW 2: 6 or 8 waves) exist for this.  Per output element every shape
 // runs the same chain of MFMAs and the same transforms: bit-identical (the batch == single tests cover it).
-struct TconvShape { int rt, rw, ntg; };
+struct TconvShape { int rt, rw, ntg, bk = WN_BK; };
 static TconvShape wino_tconv_shape(const ConvGemmArgs &a) {
-    const TconvShape dflt = wino_tconv_tiles96(a) ? TconvShape{1, 4, 3} : wino_tconv_rows128(a) ? TconvShape{2, 2, 4} : TconvShape{1, 3, 4};
+    TconvShape dflt = wino_tconv_tiles96(a) ? TconvShape{1, 4, 3} : wino_tconv_rows128(a) ? TconvShape{2, 2, 4} : TconvShape{1, 3, 4};
+    // HIPVOC_WINO_TCONV_W4=1 (experiment): 128-row x 128-tile layers in 4-wave workgroups of 64 rows, 8-channel blocks, three per CU
+    // 128-row x 128-tile layers (blocks 1 and 2) run in 4-wave workgroups of 64 rows with 8-channel blocks, three per CU (50 KB of
+    // LDS, 166 registers), so that one workgroup's barriers and epilogue overlap the others' MFMAs: 5.1 -> 4.75 ms per layer
+    // (HIPVOC_WINO_TCONV_W4=0: the 8-wave shape).  Measured out for the other two layers: block 0 in 3 waves x 64 rows x 96 tiles
+    // (4.04 -> 4.73 ms: K = 1536 is 192 barriers, and the weight tiles are fetched twice as often), block 3 in 6 waves x 96 rows x
+    // 64 tiles (4.69 -> 5.36 ms).
+    {
+        const char *e4 = getenv("HIPVOC_WINO_TCONV_W4");
+        if (dflt.rt == 2 && !(e4 && atoi(e4) == 0)) dflt = TconvShape{2, 1, 4, 8};
+    }
     const char *e = getenv("HIPVOC_WINO_TCONV_SMALL");
     const long max_wgs = e ? atol(e) : 400;
     const long n_tl = (a.M + 2) / 3;
@@ -1056,6 +1066,7 @@ const char *wino_kernel_name(const ConvGemmArgs &a) {      // as rocprofv3 print
         static char tn[2][3][5][5][36];
         const TconvShape t = wino_tconv_shape(a);
         char *n = tn[a.sn_a ? 1 : 0][t.rt][t.rw][t.ntg];
+        if (t.bk != WN_BK) return a.sn_a ? "wino_tconv_kernel<true,2,1,4,8>" : "wino_tconv_kernel<false,2,1,4,8>";
         if (!n[0]) snprintf(n, 36, "wino_tconv_kernel<%s,%d,%d,%d>", a.sn_a ? "true" : "false", t.rt, t.rw, t.ntg);
         return n;
     }
@@ -1136,9 +1147,9 @@ static hipError_t wino_ps_launch_one(const ConvGemmArgs &a, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <bool SN, int RT, int RW, int NTG>
+template <bool SN, int RT, int RW, int NTG, int BK = WN_BK>
 static hipError_t wino_tconv_launch_one(const ConvGemmArgs &a, hipStream_t s) {
-    using GEO = TconvGeom<RT, RW, NTG>;
+    using GEO = TconvGeom<RT, RW, NTG, BK>;
     const int n_tl = (a.M + 2) / 3;                          // tiles of three input steps
     const int wg_per_unit = (n_tl + GEO::NT - 1) / GEO::NT;
     const int n_tiles = a.N / GEO::BN;
@@ -1156,11 +1167,11 @@ static hipError_t wino_tconv_launch_one(const ConvGemmArgs &a, hipStream_t s) {
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 64 && !done[dev]) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(wino_tconv_kernel<SN, RT, RW, NTG>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(wino_tconv_kernel<SN, RT, RW, NTG, BK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         done[dev] = true;
     }
-    hipLaunchKernelGGL((wino_tconv_kernel<SN, RT, RW, NTG>), dim3((unsigned)grid), dim3(GEO::NTH), lds, s, a, wg_per_unit, n_tiles);
+    hipLaunchKernelGGL((wino_tconv_kernel<SN, RT, RW, NTG, BK>), dim3((unsigned)grid), dim3(GEO::NTH), lds, s, a, wg_per_unit, n_tiles);
     return hipGetLastError();
 }
 
@@ -1180,6 +1191,7 @@ hipError_t launch_wino_conv7(const ConvGemmArgs &a, hipStream_t s) {
         const bool sn = a.sn_a != nullptr;
         const TconvShape t = wino_tconv_shape(a);
 #define WT_GO(RT_, RW_, NTG_) if (t.rt == RT_ && t.rw == RW_ && t.ntg == NTG_) return sn ? wino_tconv_launch_one<true, RT_, RW_, NTG_>(a, s) : wino_tconv_launch_one<false, RT_, RW_, NTG_>(a, s)
+        if (t.bk == 8) return sn ? wino_tconv_launch_one<true, 2, 1, 4, 8>(a, s) : wino_tconv_launch_one<false, 2, 1, 4, 8>(a, s);
         WT_GO(2, 2, 4);
         WT_GO(1, 3, 4);
         WT_GO(1, 4, 3);
