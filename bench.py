@@ -389,7 +389,7 @@ def main(argv=None):
             L *= r
             dw_bytes += 2 * cfg.latent_dim * L * 4 * G                 # x in, normalised y out
         alg = {
-            "final_conv_kernel<7>": G * (cfg.decoder_dim // 16 * Lu + Lu) * 4,   # C=96 activations in, 1 channel out
+            next((k for k in kernels if k.startswith("final_conv_kernel")), "final_conv_kernel<7,false>"): G * (cfg.decoder_dim // 16 * Lu + Lu) * 4,   # C=96 activations in, 1 channel out
             next((k for k in kernels if k.startswith("dwconv_ln")), "dwconv_ln_kernel"): dw_bytes,
             next((k for k in kernels if k.startswith("rmsnorm")), "rmsnorm_kernel"): (2 * cfg.num_hidden_layers + 1) * 2 * cfg.hidden_size * G * T * 4,
             "swiglu_kernel": cfg.num_hidden_layers * 3 * cfg.intermediate_size * G * T * 4,

@@ -1102,7 +1102,7 @@ static std::unique_ptr<Plan> build_plan(Ctx *c, int G, int T, bool debug, char *
         const float *x = cur, *w = c->fin_w_raw, *bias = g.bias, *sa = act_in ? nullptr : c->fin_snake.ea, *sib = act_in ? nullptr : c->fin_snake.ib;
         int Cf = g.Cin, GG = G, LL = L, LLp = Lp;
         Ctx *cc = c;
-        b.add("final_conv7", "final_conv_kernel<7>", (double)G * L * g.Cin * g.ntaps, [=](hipStream_t s) {
+        b.add("final_conv7", sa ? "final_conv_kernel<7,true>" : "final_conv_kernel<7,false>", (double)G * L * g.Cin * g.ntaps, [=](hipStream_t s) {
             return launch_final_conv(x, cc->cur_out, w, bias, sa, sib, Cf, 7, GG, LL, LLp, cc->cur_out_stride, s);
         });
         plan->steps.back().bytes = ((double)g.Cin + 1.0) * G * L * 4;

@@ -1101,7 +1101,8 @@ hipError_t launch_dwconv_ln(const float *x, float *y, const float *dw_w, const f
 // sn_a == null: x is already activated (the last residual unit applied the final SnakeBeta in its epilogue, once per
 // element instead of 2.5 times here) and the kernel is a plain 7-tap filter over C rows.
 // -------------------------------------------------------------------------------------------------
-template <int K>
+template <int K, bool SN>      // SN: x is the raw tensor and the kernel applies the SnakeBeta itself (a compile-time choice: as a run-time
+                                // branch in the channel loop it kept hipcc from issuing the next channels' loads ahead of the arithmetic)
 __global__ __launch_bounds__(256) void final_conv_kernel(const float *x, float *out, const float *w /*[C][K]*/,
                                                           const float *bias, const float *sn_a, const float *sn_ib,
                                                           int C, int G, int L, int Lp, long out_stride,
@@ -1120,30 +1121,48 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const float *x, float *
     float b0 = bias ? bias[0] : 0.0f;
 #pragma unroll
     for (int i = 0; i < NO; i++) acc[i] = b0;
-    const bool sn = sn_a != nullptr;                  // (uniform)
-#pragma unroll 4
-    for (int c = 0; c < C; c++) {
-        const float *xr = xu + (long)c * cs;
-        float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 v0 = t >= 8 ? *reinterpret_cast<const float4 *>(xr + t - 8) : z;
-        float4 v1 = t >= 4 ? *reinterpret_cast<const float4 *>(xr + t - 4) : z;
-        float4 v2 = *reinterpret_cast<const float4 *>(xr + t);
-        float sv[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
-        if (sn) {
-            const f32x2 sa = (f32x2)(sn_a[c]), sib = (f32x2)(sn_ib[c]);
+    const int t6 = t >= 8 ? t - 6 : 0, t4 = t >= 4 ? t - 4 : 0;
+    // Channels in batches of CB: all loads of a batch are issued before its arithmetic (program order keeps them so; as one loop
+    // hipcc waited for each channel's three loads before issuing the next channel's -- three loads in flight per wave).
+    // Unconditional loads from clamped addresses, zeroed by selects: written as `t >= 8 ? load : 0` hipcc split each halo load
+    // into per-dword loads under exec-mask branches (seven load instructions and six branches per channel; found in the ISA).
+    // Positions t-6, t-5 come as one 8-byte load (t is a multiple of 4).
+    constexpr int CB = 4;
+    for (int c0 = 0; c0 < C; c0 += CB) {
+        float2 v0[CB];
+        float4 v1[CB], v2[CB];
 #pragma unroll
-            for (int i = 2; i < 12; i += 2) {         // (sv[0], sv[1] are never read: K - 1 <= 6)
-                f32x2 s2 = snake_beta2(mk2(sv[i], sv[i + 1]), sa, sib);
-                int pos = t - 8 + i;
-                sv[i] = (pos >= 0 && pos < L) ? s2.x : 0.0f;        // zero padding applies to the activation output
-                sv[i + 1] = (pos + 1 >= 0 && pos + 1 < L) ? s2.y : 0.0f;
+        for (int q = 0; q < CB; q++) {
+            const int c = c0 + q < C ? c0 + q : C - 1;
+            const float *xr = xu + (long)c * cs;
+            v0[q] = *reinterpret_cast<const float2 *>(xr + t6);
+            v1[q] = *reinterpret_cast<const float4 *>(xr + t4);
+            v2[q] = *reinterpret_cast<const float4 *>(xr + t);
+        }
+#pragma unroll
+        for (int q = 0; q < CB; q++) {
+            const bool live = c0 + q < C;                 // (a batch past the last channel: clamped loads, zero weights -- no branch,
+            const int c = live ? c0 + q : C - 1;          //  which would let hipcc sink each channel's loads to its arithmetic again)
+            const float wl = live ? 1.0f : 0.0f;
+            if (t < 8) v0[q] = make_float2(0.f, 0.f);
+            if (t < 4) v1[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            float sv[12] = {0.f, 0.f, v0[q].x, v0[q].y, v1[q].x, v1[q].y, v1[q].z, v1[q].w, v2[q].x, v2[q].y, v2[q].z, v2[q].w};
+            if constexpr (SN) {
+                const f32x2 sa = (f32x2)(sn_a[c]), sib = (f32x2)(sn_ib[c]);
+#pragma unroll
+                for (int i = 2; i < 12; i += 2) {         // (sv[0], sv[1] are never read: K - 1 <= 6)
+                    f32x2 s2 = snake_beta2(mk2(sv[i], sv[i + 1]), sa, sib);
+                    int pos = t - 8 + i;
+                    sv[i] = (pos >= 0 && pos < L) ? s2.x : 0.0f;        // zero padding applies to the activation output
+                    sv[i + 1] = (pos + 1 >= 0 && pos + 1 < L) ? s2.y : 0.0f;
+                }
+            }                                             // else: positions < 0 are the zeros above; positions >= L only reach samples >= L
+#pragma unroll
+            for (int j = 0; j < K; j++) {
+                const float wv = w[c * K + j] * wl;       // (unconditional: a uniform address stays a scalar load)
+#pragma unroll
+                for (int i = 0; i < NO; i++) acc[i] = __builtin_fmaf(wv, sv[8 + i - (K - 1) + j], acc[i]);   // sample t+i reads activation t+i-(K-1-j); an explicit fma: both instances round alike
             }
-        }                                             // else: positions < 0 are the zeros above; positions >= L only reach samples >= L
-#pragma unroll
-        for (int j = 0; j < K; j++) {
-            float wv = w[c * K + j];
-#pragma unroll
-            for (int i = 0; i < NO; i++) acc[i] += wv * sv[8 + i - (K - 1) + j];   // sample t+i reads activation t+i-(K-1-j)
         }
     }
     float *o = out + (long)u * out_stride + t;
@@ -1164,8 +1183,13 @@ hipError_t launch_final_conv(const float *x, float *out, const float *w, const f
     if (K != 7 || (Lp & 3) || ((uintptr_t)x & 15)) return hipErrorInvalidValue;
     int vec = ((out_stride & 3) == 0 && ((uintptr_t)out & 15) == 0) ? 1 : 0;
     int nthr = (L + 3) / 4;
-    hipLaunchKernelGGL(final_conv_kernel<7>, dim3((nthr + 255) / 256, G), dim3(256), 0, s, x, out, w, bias, sn_a, sn_ib, C,
-                       G, L, Lp, out_stride, vec);
+    if ((sn_a == nullptr) != (sn_ib == nullptr)) return hipErrorInvalidValue;
+    if (sn_a)
+        hipLaunchKernelGGL((final_conv_kernel<7, true>), dim3((nthr + 255) / 256, G), dim3(256), 0, s, x, out, w, bias, sn_a, sn_ib, C,
+                           G, L, Lp, out_stride, vec);
+    else
+        hipLaunchKernelGGL((final_conv_kernel<7, false>), dim3((nthr + 255) / 256, G), dim3(256), 0, s, x, out, w, bias, sn_a, sn_ib, C,
+                           G, L, Lp, out_stride, vec);
     return hipGetLastError();
 }
 

@@ -1359,7 +1359,10 @@ static hipError_t gemmd_launch_one(const ConvGemmArgs &a, hipStream_t s) {
 hipError_t launch_gemmd(const ConvGemmArgs &a, hipStream_t s) {
     if (!gemmd_selected(a)) return hipErrorInvalidValue;
     if (a.M <= 0) return hipSuccess;
-    if ((a.x_cs & 3) || (a.x_us & 3) || ((uintptr_t)a.x & 15) || ((uintptr_t)a.w & 15) || (a.NP & 3) || a.Lin < 1) return hipErrorInvalidValue;
+    // what the kernel's 16-byte DMA pieces and 32-bit byte offsets (16 rows of a channel block) assume
+    if ((a.x_cs & 3) || (a.x_us & 3) || ((uintptr_t)a.x & 15) || ((uintptr_t)a.w & 15) || (a.NP & 3) || a.Lin < 1 ||
+        16.0 * (double)a.x_cs * 4.0 + 4.0 * (double)a.Lin >= 4294967296.0 || 16.0 * (double)a.NP * 4.0 >= 4294967296.0)
+        return hipErrorInvalidValue;
     const int tn = detail::conv_gemm_launch_tn(a);
     if (gemmd_nw() == 4) {
         switch (tn) {
