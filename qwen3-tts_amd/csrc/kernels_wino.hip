@@ -1063,11 +1063,10 @@ const char *wino_kernel_name(const ConvGemmArgs &a) {      // as rocprofv3 print
         return a.shift_step == 1 ? "wino_ps_kernel<1,3,true,4,16>" : a.shift_step == 3 ? "wino_ps_kernel<3,3,true,4,16>" : "wino_ps_kernel<9,3,true,4,16>";
     }
     if (wino_tconv_selected(a)) {
-        static char tn[2][3][5][5][36];
+        static char tn[2][3][5][5][2][40];                  // (all five template arguments, as rocprofv3 prints the symbol)
         const TconvShape t = wino_tconv_shape(a);
-        char *n = tn[a.sn_a ? 1 : 0][t.rt][t.rw][t.ntg];
-        if (t.bk != WN_BK) return a.sn_a ? "wino_tconv_kernel<true,2,1,4,8>" : "wino_tconv_kernel<false,2,1,4,8>";
-        if (!n[0]) snprintf(n, 36, "wino_tconv_kernel<%s,%d,%d,%d>", a.sn_a ? "true" : "false", t.rt, t.rw, t.ntg);
+        char *n = tn[a.sn_a ? 1 : 0][t.rt][t.rw][t.ntg][t.bk == 8];
+        if (!n[0]) snprintf(n, 40, "wino_tconv_kernel<%s,%d,%d,%d,%d>", a.sn_a ? "true" : "false", t.rt, t.rw, t.ntg, t.bk);
         return n;
     }
     static char names[2][3][5][44];

@@ -476,7 +476,7 @@ def test_layout_and_placement_switches_do_not_change_a_bit(pkg, synth, monkeypat
         if "HIPVOC_WINO_TCONV_SMALL" in env:
             assert not any(n.startswith("wino_tconv_kernel<false,1,2,") for n in names), names
         if "HIPVOC_WINO_TCONV_W4" in env:
-            assert not any(n.endswith(",8>") and n.startswith("wino_tconv_kernel") for n in names) and any(n.startswith("wino_tconv_kernel<false,2,2,4>") for n in names), names
+            assert not any(n.endswith(",8>") and n.startswith("wino_tconv_kernel") for n in names) and any(n.startswith("wino_tconv_kernel<false,2,2,4,") for n in names), names
         if "HIPVOC_GEMMDS_NW" in env:
             assert any(n.startswith("gemm_dmas_kernel<1,1,8>") for n in names), names
         assert np.array_equal(small.view(np.uint32), ref_small.view(np.uint32)), env
