@@ -1051,6 +1051,17 @@ bool wino_selected(const ConvGemmArgs &a) {
 }
 
 static int wino_rt();
+// Small launches of the default conv7 form (a single utterance: decoder[0] is 96 workgroups, block 0's layers 384, for 768 slots):
+// one row tile per wave instead of two -- twice the workgroups, each wave's MFMA chain half as long.  Used when the two-tile grid
+// is at most HIPVOC_WINO_PS_SMALL workgroups (default 448; 0: never).  Same chains per output element: bit-identical.
+static bool wino_ps_rt1(const ConvGemmArgs &a) {
+    const char *e = getenv("HIPVOC_WINO_PS_SMALL");
+    const long max_wgs = e ? atol(e) : 448;
+    const int d = a.shift_step;
+    if (max_wgs <= 0 || a.sn_a || d == 9) return false;      // (dilation 9: the window's 54-position halo outweighs it -- 0.217 -> 0.239 ms on block 0)
+    const long n_pairs = (a.M + 2 * d - 1) / (2 * d) * d, wgs = ((n_pairs + 63) / 64) * (long)a.units * (a.N / 64);
+    return wgs <= max_wgs;
+}
 // HIPVOC_WINO_UNIT_WG: shape of the fused Winograd unit: 8 = 8 waves, 128 tiles, 16-channel blocks, one workgroup per CU;
 // 4 = 4 waves, 64 tiles, 8-channel blocks, two-phase exchange, two workgroups per CU
 static bool wino_unit_small() {
@@ -1071,6 +1082,7 @@ const char *wino_kernel_name(const ConvGemmArgs &a) {      // as rocprofv3 print
     }
     static char names[2][3][5][44];
     const int di = a.shift_step == 1 ? 0 : a.shift_step == 3 ? 1 : 2, sn = a.sn_a ? 1 : 0, mode = sn && (wino_rt() == 3 || wino_rt() == 5) ? 1 : wino_rt();
+    if (mode == 5 && wino_ps_rt1(a)) return di == 0 ? "wino_ps_kernel<1,1,false,2,8>" : di == 1 ? "wino_ps_kernel<3,1,false,2,8>" : "wino_ps_kernel<9,1,false,2,8>";
     const int mi = mode == 1 ? 0 : mode == 2 ? 1 : mode == 4 ? 2 : mode == 3 ? 3 : 4;
     char *n = names[sn][di][mi];
     if (!n[0]) {
@@ -1206,6 +1218,7 @@ hipError_t launch_wino_conv7(const ConvGemmArgs &a, hipStream_t s) {
     const bool sn = a.sn_a != nullptr;
     const int mode = sn && (wino_rt() == 3 || wino_rt() == 5) ? 1 : wino_rt();
     if (mode == 3) return a.shift_step == 1 ? wino_ps_launch_one<1, 2, false, 4, 16>(a, s) : a.shift_step == 3 ? wino_ps_launch_one<3, 2, false, 4, 16>(a, s) : wino_ps_launch_one<9, 2, false, 4, 16>(a, s);
+    if (mode == 5 && wino_ps_rt1(a)) return a.shift_step == 1 ? wino_ps_launch_one<1, 1, false, 2, 8>(a, s) : a.shift_step == 3 ? wino_ps_launch_one<3, 1, false, 2, 8>(a, s) : wino_ps_launch_one<9, 1, false, 2, 8>(a, s);
     if (mode == 5) return a.shift_step == 1 ? wino_ps_launch_one<1, 2, false, 2, 8>(a, s) : a.shift_step == 3 ? wino_ps_launch_one<3, 2, false, 2, 8>(a, s) : wino_ps_launch_one<9, 2, false, 2, 8>(a, s);
 #define WN_GO2(D_, SN_) (mode == 1 ? wino_launch_one<D_, SN_, 1, 2>(a, s) : mode == 2 ? wino_launch_one<D_, SN_, 2, 1>(a, s) : wino_launch_one<D_, SN_, 1, 1>(a, s))
 #define WN_GO(D_) (sn ? WN_GO2(D_, true) : WN_GO2(D_, false))

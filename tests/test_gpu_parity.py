@@ -439,6 +439,7 @@ def test_layout_and_placement_switches_do_not_change_a_bit(pkg, synth, monkeypat
                                  kernel instances -- which must really have run);
       HIPVOC_WINO_TCONV_SMALL=0  fp32: the trans-convs' large-launch workgroup shapes on a small launch too;
       HIPVOC_WINO_TCONV_W4=0     fp32: blocks 1/2's trans-convs in 8-wave workgroups of 16-channel blocks instead of 4-wave / 8-channel ones;
+      HIPVOC_WINO_PS_SMALL=0     fp32: two row tiles per wave in the conv7 kernels on small launches too (default there: one);
       HIPVOC_GEMMDS_NW=1, HIPVOC_GEMM1_DMA=1   fp32: one-wave workgroups of gemm_dmas_kernel; gemm1_kernel for the layers the
                                  LDS-DMA kernels otherwise take."""
     cfg = synth.FULL
@@ -465,10 +466,11 @@ def test_layout_and_placement_switches_do_not_change_a_bit(pkg, synth, monkeypat
         assert any(n.startswith("gemm_dmas_kernel<1,2,8>") for n in ref_names), ref_names
         assert any(n.startswith("wino_tconv_kernel<false,1,2,") for n in ref_names), ref_names       # a 64-row small-launch shape
         assert "wino_tconv_kernel<false,2,1,4,8>" in ref_names, ref_names
+        assert "wino_ps_kernel<1,1,false,2,8>" in ref_names, ref_names                                # decoder[0] / block 0 on one utterance
     else:
         assert any("_oi_kernel<" in n for n in ref_names) and any("_pt_kernel<" in n for n in ref_names), ref_names
     switches = [{"HIPVOC_FIN_POST": "0"}]
-    switches += [{"HIPVOC_WINO_TCONV_SMALL": "0"}, {"HIPVOC_WINO_TCONV_W4": "0"}, {"HIPVOC_GEMMDS_NW": "1"}, {"HIPVOC_GEMM1_DMA": "1"}] if dtype == 0 else [{"HIPVOC_TCONV_OI": "0"}]
+    switches += [{"HIPVOC_WINO_TCONV_SMALL": "0"}, {"HIPVOC_WINO_TCONV_W4": "0"}, {"HIPVOC_WINO_PS_SMALL": "0"}, {"HIPVOC_GEMMDS_NW": "1"}, {"HIPVOC_GEMM1_DMA": "1"}] if dtype == 0 else [{"HIPVOC_TCONV_OI": "0"}]
     for env in switches:
         small, big, names = run(env)
         if "HIPVOC_TCONV_OI" in env:
@@ -477,6 +479,8 @@ def test_layout_and_placement_switches_do_not_change_a_bit(pkg, synth, monkeypat
             assert not any(n.startswith("wino_tconv_kernel<false,1,2,") for n in names), names
         if "HIPVOC_WINO_TCONV_W4" in env:
             assert not any(n.endswith(",8>") and n.startswith("wino_tconv_kernel") for n in names) and any(n.startswith("wino_tconv_kernel<false,2,2,4,") for n in names), names
+        if "HIPVOC_WINO_PS_SMALL" in env:
+            assert not any(n.startswith("wino_ps_kernel<") and ",1,false,2,8>" in n for n in names), names
         if "HIPVOC_GEMMDS_NW" in env:
             assert any(n.startswith("gemm_dmas_kernel<1,1,8>") for n in names), names
         assert np.array_equal(small.view(np.uint32), ref_small.view(np.uint32)), env
