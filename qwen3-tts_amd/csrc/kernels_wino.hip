@@ -1350,10 +1350,29 @@ static int gemmd_nw() {
     return (e ? atoi(e) : GEMMD_NW_DEFAULT) == 4 ? 4 : 8;
 }
 
+// Tile height of a launch: conv_gemm_launch_tn's, except on small launches (a few rounds of the chip's workgroup slots), where the
+// height with the fewest rounds x rows wins -- block 2's 1x1 conv on one utterance is 1 280 workgroups of 96 rows for 1 024 slots
+// (two rounds for 1.25); 1 920 of 64 rows run two rounds of two thirds the length.  Any height gives the same bits.
+static int gemmd_tn(const ConvGemmArgs &a) {
+    const int tn0 = detail::conv_gemm_launch_tn(a);
+    const int bm = 32 * gemmd_nw();
+    const long slots = gemmd_nw() == 4 ? 1024 : 512, tiles_m = (long)((a.M + bm - 1) / bm) * a.units;
+    auto wgs = [&](int t) { return tiles_m * (a.NP / (32 * t)); };
+    if (tn0 <= 1 || wgs(tn0) <= slots || wgs(tn0) > 4 * slots) return tn0;      // (one round, or many: as it is)
+    int best = tn0;
+    long best_cost = ((wgs(tn0) + slots - 1) / slots) * tn0;
+    for (int t = tn0 - 1; t >= 1; t--) {
+        if (a.NP % (32 * t)) continue;
+        const long c = ((wgs(t) + slots - 1) / slots) * t;
+        if (c < best_cost) { best = t; best_cost = c; }
+    }
+    return best;
+}
+
 const char *gemmd_kernel_name(const ConvGemmArgs &a) {
     static const char *n[2][5] = {{"", "gemm_dma_kernel<1,8>", "gemm_dma_kernel<2,8>", "gemm_dma_kernel<3,8>", "gemm_dma_kernel<4,8>"},
                                   {"", "gemm_dma_kernel<1,4>", "gemm_dma_kernel<2,4>", "gemm_dma_kernel<3,4>", "gemm_dma_kernel<4,4>"}};
-    const int tn = detail::conv_gemm_launch_tn(a);
+    const int tn = gemmd_tn(a);
     return n[gemmd_nw() == 4][tn >= 1 && tn <= 4 ? tn : 4];
 }
 
@@ -1375,7 +1394,7 @@ hipError_t launch_gemmd(const ConvGemmArgs &a, hipStream_t s) {
     if ((a.x_cs & 3) || (a.x_us & 3) || ((uintptr_t)a.x & 15) || ((uintptr_t)a.w & 15) || (a.NP & 3) || a.Lin < 1 ||
         16.0 * (double)a.x_cs * 4.0 + 4.0 * (double)a.Lin >= 4294967296.0 || 16.0 * (double)a.NP * 4.0 >= 4294967296.0)
         return hipErrorInvalidValue;
-    const int tn = detail::conv_gemm_launch_tn(a);
+    const int tn = gemmd_tn(a);
     if (gemmd_nw() == 4) {
         switch (tn) {
             case 1: return gemmd_launch_one<1, 4>(a, s);
