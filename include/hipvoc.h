@@ -143,9 +143,14 @@ int hipvoc_sync(void *h);
  * creation happens in the call (the first call for a given n_units builds its launch plan, host memory only).
  * Limit: the pass must fit the array -- with the full-size decoder, 2 units of 64 frames (one 10 s utterance) in
  * fp32 and bf16, 4 in bf16x3; never more than 128 units.  Larger requests fail with HIPVOC_E_SCRATCH and the
- * needed size in hipvoc_last_error; nothing is launched.  The array is cleared at the start of every call.  All
- * handles on one GPU share that GPU's array: calls that overlap on one GPU (two handles, two threads) race -- keep
- * them serialised.  Work is enqueued on the handle's stream like hipvoc_decode_units_device.
+ * needed size in hipvoc_last_error; nothing is launched.  The array keeps the last call's contents and is NOT
+ * cleared: nothing in it has to start at zero (every byte a result depends on is written by the pass's own kernels
+ * first).  All handles on one GPU share that GPU's array.  The library orders their passes ON THE DEVICE: each call
+ * makes its stream wait for the previous no-alloc pass on that GPU (one event per GPU, created by hipvoc_load) and holds
+ * a per-GPU host lock while it enqueues, so two handles (the worker's --contexts 2) called one after the other without a
+ * sync in between do not overlap in the array.  What still races: reading d_out, or reusing d_codes, before the
+ * handle's own stream has finished (hipvoc_sync), as with hipvoc_decode_units_device.  Work is enqueued on the handle's
+ * stream like hipvoc_decode_units_device.
  */
 #define HIPVOC_NOALLOC_SCRATCH_BYTES (384u << 20)
 int hipvoc_decode_units_device_noalloc(void *h, const int64_t *d_codes, int n_units, float *d_out, size_t unit_stride);

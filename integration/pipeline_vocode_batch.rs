@@ -145,8 +145,18 @@ impl VocoderQueue {
 // synthesize_pipelined (pipeline.rs:346-377): `voc_rx.push(self.vocoder.submit(encode_i64(&flat), n_chunk_tokens))` per
 // text chunk, no "keep one in flight" drain (the queue does the pacing), and the same in-order await loop at the end.
 //
-// api/openai.rs:86 and mcp/server.rs:243: `Pipeline::synthesize` takes the guard itself --
+// ---- DESIGN NOTE, not a patch ------------------------------------------------------------------------------------------------
+// What follows does not exist in the reference and is NOT written out here: `Pipeline::generate` / `Pipeline::collect_audio`
+// are names for the two halves a maintainer would cut `synthesize_single` (pipeline.rs:403-692) and `synthesize_pipelined`
+// (pipeline.rs:180-400) into -- everything up to and including the tail submit (pipeline.rs:644-657 / 347-353) on one side, the
+// in-order response loop (pipeline.rs:659-673 / 356-377) and the RTF log lines (679-684 / 385-392) on the other.  The split
+// moves ~20 local variables (timers, `all_codes`, `vocode_batches_sent`) across the cut; it needs a compiler to get right, so
+// it is left as this note.  The code ABOVE this line (VocoderQueue and the call-site substitutions) is the patch.
+//
+// api/openai.rs:86 and mcp/server.rs:243 hold `synthesis_lock` around the whole `Pipeline::synthesize`; with the split the guard
+// would cover only the talker / predictor phases:
 //     let guard = state.synthesis_lock.clone().lock_owned().await;          // phases 1-3: talker / predictor are single-client
 //     let (codes, voc_rx) = pipeline.generate(&params).await?;               // submits vocoder work as it goes
 //     drop(guard);                                                          // the next request's generation starts here
 //     let audio = pipeline.collect_audio(voc_rx).await?;                     // phase 4 overlaps it
+// Without the split the queue still coalesces: concurrent `speak` CLI processes and several frontends share one vocoder worker.

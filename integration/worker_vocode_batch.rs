@@ -1,28 +1,34 @@
 // Source of the `hip-vocoder` feature's Rust side.  Written against the reference tree; NOT compiled
 // here (this image has no cargo / rustc).  Three fragments: the worker's VocodeBatch handler, model discovery, download.
 
-// ---- src/worker/mod.rs, Worker::dispatch (mod.rs:288): one more arm --------------------------------------------------
-//     Request::VocodeBatch { codes, n_tokens } => self.handle_vocode_batch(codes, n_tokens).await,
+// ---- src/worker/mod.rs, Worker::dispatch (mod.rs:260-294): one more arm, beside `Request::Vocode` (mod.rs:288) ---------
+//     Request::VocodeBatch { codes, n_tokens } => self.handle_vocode_batch(&codes, &n_tokens),
+// (dispatch is a sync `fn dispatch(&mut self, req: Request) -> Result<Response>`; every handler returns
+//  `Result<Response>` built by `ok(ResponseData::..)`, mod.rs:702-708.)
 
 impl Worker {
     /// Several sequences, one batched GPU decode.  Per sequence exactly what handle_vocode
     /// (mod.rs:507-531) does: LE bytes -> i64, synthesize, f32 -> i16 -> LE bytes; a sequence with fewer code bytes than
-    /// n_tokens*16*8 is an error response instead of the slice panic of mod.rs:513-516.
-    async fn handle_vocode_batch(&mut self, codes: Vec<Vec<u8>>, n_tokens: Vec<usize>) -> Result<ResponseData> {
+    /// n_tokens*16*8 is an error response instead of the silent truncation of mod.rs:513-516's chunks_exact.
+    fn handle_vocode_batch(&mut self, codes: &[Vec<u8>], n_tokens: &[usize]) -> Result<Response> {
+        let voc = match &mut self.state {                                   // as handle_vocode, mod.rs:508-511
+            WorkerState::Vocoder(vs) => &mut vs.vocoder,
+            _ => anyhow::bail!("This worker does not have a vocoder"),
+        };
         if codes.len() != n_tokens.len() {
             anyhow::bail!("VocodeBatch: {} code buffers but {} token counts", codes.len(), n_tokens.len());
         }
-        let vocoder = self.vocoder.as_mut().ok_or_else(|| anyhow::anyhow!("Vocoder not initialized"))?;
         let mut seqs: Vec<Vec<i64>> = Vec::with_capacity(codes.len());
-        for (bytes, &n) in codes.iter().zip(&n_tokens) {
-            if bytes.len() < n * 16 * 8 {
+        for (bytes, &n) in codes.iter().zip(n_tokens) {
+            let need = n.checked_mul(16 * 8).ok_or_else(|| anyhow::anyhow!("VocodeBatch: n_tokens overflows"))?;
+            if bytes.len() < need {
                 anyhow::bail!("VocodeBatch: codes shorter than n_tokens*16");
             }
-            seqs.push(bytes[..n * 16 * 8].chunks_exact(8)
+            seqs.push(bytes[..need].chunks_exact(8)
                 .map(|c| i64::from_le_bytes([c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]]))
                 .collect());
         }
-        let waves = vocoder.synthesize_batch(&seqs, &n_tokens)?;       // vocoder.rs: see hip_vocoder.rs
+        let waves = voc.synthesize_batch(&seqs, n_tokens)?;                 // vocoder.rs: below and hip_vocoder.rs
         let mut audio = Vec::with_capacity(waves.len());
         let mut n_samples = Vec::with_capacity(waves.len());
         for w in waves {
@@ -30,7 +36,7 @@ impl Worker {
             n_samples.push(pcm.len());
             audio.push(pcm.iter().flat_map(|s| s.to_le_bytes()).collect::<Vec<u8>>());
         }
-        Ok(ResponseData::VocodeBatch { audio, n_samples })
+        ok(ResponseData::VocodeBatch { audio, n_samples })
     }
 }
 

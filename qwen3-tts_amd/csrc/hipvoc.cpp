@@ -1512,7 +1512,7 @@ int hipvoc_decode_units_device(void *h, const int64_t *d_codes, int n_units, flo
 
 // No counterpart in the reference: for callers that cannot allocate (HIP graph capture, tight serving loops).  Same
 // kernels and launch plan as hipvoc_decode_units_device; the workspace is this device's copy of the static scratch array
-// (scratch.hip), cleared at the start of every call.  No hipMalloc / hipFree / event creation on this path.
+// (scratch.hip).  No hipMalloc / hipFree / event creation on this path.
 int hipvoc_decode_units_device_noalloc(void *h, const int64_t *d_codes, int n_units, float *d_out, size_t unit_stride) {
     return guarded(h, [&]() -> int {
         DEC(h);
@@ -1523,11 +1523,19 @@ int hipvoc_decode_units_device_noalloc(void *h, const int64_t *d_codes, int n_un
         if (!c->scratch) { c->err = "static scratch not bound"; return HIPVOC_E_HIP; }
         Plan *p = get_plan(c, n_units, c->unit_frames, false, true);      // host-side bookkeeping only; refuses what does not fit
         if (!p) return HIPVOC_E_SCRATCH;
-        // every call on this GPU shares the array and finds the last call's contents in it
-        HIPCHK(hipMemsetAsync(c->scratch, 0, p->scratch_used, c->stream));
+        // Every call on this GPU shares the array and finds the last call's contents in it.  Nothing in it has to start at
+        // zero: every byte a kernel's result depends on is written by this pass's own producers first; what else a
+        // kernel may touch is row padding (positions [L, Lp) and the 64-float slack of a buffer), which holds finite
+        // values of an earlier pass (zeros at program start) and only ever reaches outputs that are not stored -- the same
+        // state the allocating entry point's buffers are in when plans of different sizes reuse them.  (Round 2 cleared
+        // the whole carve-out here: 0.08 ms of HBM writes per call for nothing.)
+        // Passes of different handles on this device are chained on the device (scratch.hip): the array is one.
+        HIPCHK(scratch_pass_begin(c->device, c->stream));
         const bool prof = c->profile;
         c->profile = false;                                               // profiling creates events
         int rc = run_plan(c, p, (const long long *)d_codes, d_out, (long)unit_stride, -1, nullptr);
+        hipError_t ee = scratch_pass_end(c->device, c->stream);
+        if (!rc && ee != hipSuccess) { c->err = fmt("hipEventRecord: %s", hipGetErrorString(ee)); rc = HIPVOC_E_HIP; }
         c->profile = prof;
         return rc;
     });

@@ -9,6 +9,7 @@
 #include "kernels.h"
 #include "device_common.h"
 
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 
@@ -406,7 +407,7 @@ size_t conv_gemm_lds_bytes(const ConvGemmArgs &a) {
 template <int TN, bool FUSE, int NW, bool ENC = false>
 static hipError_t conv_gemm_launch_one(const ConvGemmArgs &a, int HL, int XW, int tiles_per_unit, int n_tiles,
                                        long grid, size_t lds, hipStream_t s) {
-    static bool done[64] = {};
+    static std::atomic<bool> done[64] = {};      // (the worker calls from several threads per device)
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;

@@ -15,6 +15,7 @@
 #include "device_common.h"
 #include "kernels.h"
 
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 
@@ -493,7 +494,7 @@ const char *conv_gemm_bf16_kernel_name(const ConvGemmArgs &a) {
 template <int TN, bool FUSE, bool XB>
 static hipError_t launch_one_bf16(const ConvGemmArgs &a, int HL, int XW, int tiles_per_unit, int n_tiles, long grid,
                                   size_t lds, hipStream_t s) {
-    static bool done[64] = {};
+    static std::atomic<bool> done[64] = {};      // (the worker calls from several threads per device)
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
@@ -511,7 +512,7 @@ static hipError_t launch_one_bf16(const ConvGemmArgs &a, int HL, int XW, int til
 // (any kernel of this file's signature: the one-off raise of the dynamic LDS limit per device, then the launch)
 template <auto KERN>
 static hipError_t launch_fn_bf16(const ConvGemmArgs &a, int HL, int XW, int tiles_per_unit, int n_tiles, long grid, size_t lds, hipStream_t s) {
-    static bool done[64] = {};
+    static std::atomic<bool> done[64] = {};      // (the worker calls from several threads per device)
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
@@ -527,7 +528,7 @@ static hipError_t launch_fn_bf16(const ConvGemmArgs &a, int HL, int XW, int tile
 template <int TN, bool FUSE>
 static hipError_t launch_one_bf16x3(const ConvGemmArgs &a, int HL, int XW, int tiles_per_unit, int n_tiles, long grid,
                                     size_t lds, hipStream_t s) {
-    static bool done[64] = {};
+    static std::atomic<bool> done[64] = {};      // (the worker calls from several threads per device)
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;

@@ -14,6 +14,7 @@
 #include "kernels.h"
 #include "device_common.h"
 
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 
@@ -196,7 +197,7 @@ const char *gemm1_kernel_name(const ConvGemmArgs &a) {
 
 template <int TN, bool ENC>
 static hipError_t gemm1_launch_one(const ConvGemmArgs &a, int tiles_per_unit, int n_tiles, long grid, size_t lds, hipStream_t s) {
-    static bool done[64] = {};
+    static std::atomic<bool> done[64] = {};      // (the worker calls from several threads per device)
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
@@ -453,7 +454,7 @@ const char *convs_kernel_name(const ConvGemmArgs &a) {
 
 template <int TN, int CB>
 static hipError_t convs_launch_one(const ConvGemmArgs &a, int HL, int XW, int tiles_per_unit, int n_tiles, long grid, size_t lds, hipStream_t s) {
-    static bool done[64] = {};
+    static std::atomic<bool> done[64] = {};      // (the worker calls from several threads per device)
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
@@ -680,7 +681,7 @@ const char *gemm1_bf16_kernel_name(const ConvGemmArgs &a) {
 
 template <int TN, bool X3>
 static hipError_t gemm1_bf16_launch_one(const ConvGemmArgs &a, int tiles_per_unit, int n_tiles, long grid, size_t lds, hipStream_t s) {
-    static bool done[64] = {};
+    static std::atomic<bool> done[64] = {};      // (the worker calls from several threads per device)
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
@@ -935,7 +936,7 @@ const char *convs_bf16_kernel_name(const ConvGemmArgs &a) {
 }
 
 static hipError_t convs_bf16x3_launch(const ConvGemmArgs &a, int HL, int XW, int tiles_per_unit, int n_tiles, long grid, size_t lds, hipStream_t s) {
-    static bool done[64] = {};
+    static std::atomic<bool> done[64] = {};      // (the worker calls from several threads per device)
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
@@ -950,7 +951,7 @@ static hipError_t convs_bf16x3_launch(const ConvGemmArgs &a, int HL, int XW, int
 
 template <bool XB>
 static hipError_t convs_bf16_launch_one(const ConvGemmArgs &a, int HL, int XW, int tiles_per_unit, int n_tiles, long grid, size_t lds, hipStream_t s) {
-    static bool done[64] = {};
+    static std::atomic<bool> done[64] = {};      // (the worker calls from several threads per device)
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;

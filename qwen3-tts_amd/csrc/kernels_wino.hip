@@ -35,6 +35,7 @@
 #include "kernels.h"
 #include "device_common.h"
 
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 
@@ -1121,7 +1122,7 @@ static hipError_t wino_launch_one(const ConvGemmArgs &a, hipStream_t s) {
     // first one, the window starts at most 6D + 3 before it and the last read is D past the base: XW >= 257 + 10 D.
     const size_t lds = sizeof(float) * (4 * GEO::BN + (SN ? 2 * (size_t)a.Cin : 0) + 2 * (size_t)GEO::XBUF + 2 * (size_t)GEO::WBUF);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    static bool done[64] = {};
+    static std::atomic<bool> done[64] = {};      // (the worker calls from several threads per device)
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
@@ -1145,7 +1146,7 @@ static hipError_t wino_ps_launch_one(const ConvGemmArgs &a, hipStream_t s) {
     if (grid > 0x7fffffffL) return hipErrorInvalidValue;
     const size_t lds = sizeof(float) * ((FUSE ? 6 : 4) * GEO::BN + (size_t)GEO::WORK(FUSE));
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    static bool done[64] = {};
+    static std::atomic<bool> done[64] = {};      // (the worker calls from several threads per device)
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
@@ -1173,7 +1174,7 @@ static hipError_t wino_tconv_launch_one(const ConvGemmArgs &a, hipStream_t s) {
     if (lt > work) work = lt;
     const size_t lds = sizeof(float) * (4 * GEO::BN + (SN ? 2 * (size_t)a.Cin : 0) + work);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    static bool done[64] = {};
+    static std::atomic<bool> done[64] = {};      // (the worker calls from several threads per device)
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;

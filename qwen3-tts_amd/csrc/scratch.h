@@ -13,4 +13,9 @@ namespace hipvoc {
 // Device address and size of `device`'s copy of the scratch array.  The first call for a device resolves the symbol and
 // must be made with that device current (hipvoc_load does); later calls return the cached pointer.
 hipError_t scratch_bind(int device, void **ptr, size_t *bytes);
+// Brackets of one pass over `device`'s array, enqueued on `stream`: begin makes the stream wait for the previous pass on
+// that device (whatever handle / stream it ran on) and takes the device's host lock; end records the pass's completion
+// and releases the lock.  Neither allocates (the event is created by scratch_bind).  end must follow a successful begin.
+hipError_t scratch_pass_begin(int device, hipStream_t stream);
+hipError_t scratch_pass_end(int device, hipStream_t stream);
 }

@@ -21,6 +21,13 @@ namespace hipvoc {
 
 static std::mutex g_scratch_mu;
 static void *g_scratch_ptr[HIPVOC_SCRATCH_MAX_DEVICES];      // per device: resolved address of that device's copy
+// Ordering of the passes that share one device's array.  Every handle enqueues on its own non-blocking stream, so a host
+// that serialises its CALLS (as the reference's per-worker mutex does) would still have two handles' kernels overlapping
+// on the GPU.  One disable-timing event per device, created at bind time (hipvoc_load), chains them: a pass waits for the
+// event of the previous pass on that device and records it again behind its own last kernel.  The per-device mutex covers
+// wait .. record, so the chain has one order.
+static hipEvent_t g_scratch_ev[HIPVOC_SCRATCH_MAX_DEVICES];
+static std::mutex g_scratch_order_mu[HIPVOC_SCRATCH_MAX_DEVICES];
 
 hipError_t scratch_bind(int device, void **ptr, size_t *bytes) {
     *ptr = nullptr;
@@ -36,11 +43,29 @@ hipError_t scratch_bind(int device, void **ptr, size_t *bytes) {
         e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
         if (e != hipSuccess) return e;
         if (!p) return hipErrorInvalidSymbol;
+        hipEvent_t ev = nullptr;
+        e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (e != hipSuccess) return e;
+        g_scratch_ev[device] = ev;
         g_scratch_ptr[device] = p;
     }
     *ptr = g_scratch_ptr[device];
     *bytes = HIPVOC_SCRATCH_BYTES;
     return hipSuccess;
+}
+
+hipError_t scratch_pass_begin(int device, hipStream_t stream) {
+    if (device < 0 || device >= HIPVOC_SCRATCH_MAX_DEVICES || !g_scratch_ev[device]) return hipErrorInvalidDevice;
+    g_scratch_order_mu[device].lock();
+    hipError_t e = hipStreamWaitEvent(stream, g_scratch_ev[device], 0);      // (an event never recorded yet: no wait)
+    if (e != hipSuccess) g_scratch_order_mu[device].unlock();
+    return e;
+}
+
+hipError_t scratch_pass_end(int device, hipStream_t stream) {
+    hipError_t e = hipEventRecord(g_scratch_ev[device], stream);
+    g_scratch_order_mu[device].unlock();
+    return e;
 }
 
 }  // namespace hipvoc

@@ -148,7 +148,7 @@ static void gpu_service(Gpu *g) {
             for (Job *j : take) { j->rc = -9; j->buf.reset(); }
         }
         long frames = 0;
-        for (Job *j : take) frames += j->n_frames;
+        for (Job *j : take) frames += j->n_frames > 0 ? j->n_frames : 1;      // the weight run_jobs charged (an empty item counts 1)
         g->load -= frames;
         for (Job *j : take) {
             Latch *l = j->latch;

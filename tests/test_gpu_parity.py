@@ -487,3 +487,29 @@ def test_layout_and_placement_switches_do_not_change_a_bit(pkg, synth, monkeypat
         for x, y in zip(big, ref_big):
             assert np.array_equal(np.asarray(x).view(np.uint32), np.asarray(y).view(np.uint32)), env
     assert np.array_equal(np.asarray(ref_big[0]).view(np.uint32), ref_small.view(np.uint32))           # batch == single
+
+
+# ------------------------------------------------------------------------------------ the static archive on the GPU
+def test_static_archive_host_decodes_the_golden_chunks(pkg, synth, tmp_path):
+    """libhipvoc.a linked into a plain-C host as build.rs would link it (tests/native/static_link_host.c): one
+    hipvoc_decode of the golden 10-frame sequence in 4-frame units.  Every kernel object's fat binary has to have
+    registered through the archive for this to produce the golden waveform."""
+    import subprocess
+    host = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "qwen3-tts_amd", "static_link_host")
+    assert os.path.exists(host), "built by `make -C qwen3-tts_amd/csrc`"
+    g = load_golden("small_chunks_10x4")
+    cfg = getattr(synth, str(g["cfg"]))
+    wpath = str(tmp_path / "w.safetensors")
+    synth.save_safetensors(wpath, weights_for(synth, str(g["cfg"]), int(g["wseed"])), cfg.metadata())
+    cpath, opath = str(tmp_path / "codes.bin"), str(tmp_path / "out.bin")
+    g["codes"].astype("<i8").tofile(cpath)
+    r = subprocess.run([host, "decode", wpath, cpath, str(g["codes"].shape[0]), str(int(g["max_tokens"])), opath],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    wav = np.fromfile(opath, dtype="<f4")
+    assert wav.size == g["wav"].size
+    assert np.abs(wav - g["wav"]).max() <= WAV_MAX_ABS
+    assert snr_db(g["wav"], wav) >= WAV_SNR_DB
+    # and bit-equal to the shared library's result on the same inputs
+    v = voc_for(pkg, synth, str(g["cfg"]), int(g["wseed"]), int(g["max_tokens"]))
+    assert np.array_equal(v.synthesize(g["codes"]).view(np.uint32), wav.view(np.uint32))

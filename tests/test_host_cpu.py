@@ -259,3 +259,34 @@ def test_load_error_text_is_per_thread(pkg):
     assert seen[0] == {"weights_path is NULL"}
     assert len(seen[1]) == 1 and "dtype" in next(iter(seen[1]))
     assert len(seen[2]) == 1
+
+
+# ------------------------------------------------------------------------------------ the static-link recipe
+STATIC_HOST = os.path.join(ROOT, "qwen3-tts_amd", "static_link_host")
+
+
+def test_static_archive_links_a_plain_c_host_as_build_rs_says(tmp_path):
+    """integration/build_rs_fragment.rs links `static=hipvoc`, `dylib=amdhip64`, `dylib=stdc++`.  csrc/Makefile builds
+    libhipvoc.a and links tests/native/static_link_host.c (plain C) with exactly those; here: the link line still says so,
+    the binary does not depend on libhipvoc.so, and it runs -- device count, find_vocoder_model on a models directory,
+    and a failing hipvoc_load whose error text comes back through hipvoc_last_error(NULL)."""
+    mk = open(os.path.join(ROOT, "qwen3-tts_amd", "csrc", "Makefile")).read()
+    link = [l for l in mk.splitlines() if "static_link_host.o" in l and " -o $@" in l]
+    assert link and "-Wl,-Bstatic -lhipvoc -Wl,-Bdynamic" in link[0] and "-lamdhip64" in link[0] and "-lstdc++" in link[0]
+    assert link[0].lstrip().startswith("gcc "), "the host must be linked by a plain C driver, as rustc's cc would"
+    frag = open(os.path.join(ROOT, "integration", "build_rs_fragment.rs")).read()
+    for want in ("static=hipvoc", "dylib=amdhip64", "dylib=stdc++", "../libhipvoc.a"):
+        assert want in frag
+    assert os.path.exists(STATIC_HOST), "run `make -C qwen3-tts_amd/csrc` (or __graft_entry__.build())"
+    assert os.path.exists(os.path.join(ROOT, "qwen3-tts_amd", "libhipvoc.a"))
+    ldd = subprocess.run(["ldd", STATIC_HOST], capture_output=True, text=True).stdout
+    assert "libhipvoc" not in ldd and "libamdhip64" in ldd and "libstdc++" in ldd, ldd
+    models = tmp_path / "models"
+    (models / "vocoder").mkdir(parents=True)
+    (models / "vocoder" / "vocoder.safetensors").write_bytes(b"")
+    r = subprocess.run([STATIC_HOST, "probe", str(models)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = dict(l.split(" ", 1) for l in r.stdout.strip().splitlines())
+    assert int(out["device_count"]) >= 0
+    assert out["find_vocoder_model"].startswith("rc=0 ") and out["find_vocoder_model"].endswith("vocoder/vocoder.safetensors")
+    assert len(out["load_error"]) > 8 and out["load_error"] != "(empty)"

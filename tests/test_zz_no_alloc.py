@@ -89,3 +89,43 @@ def test_noalloc_full_size_two_calls_second_smaller(pkg, synth):
     ref1b, got1b = _both(v, _units(synth, cfg, 1, 64, 2000))
     assert np.array_equal(got1b.view(np.uint32), got1.view(np.uint32))
     v.close()
+
+
+def test_noalloc_two_handles_on_one_gpu_back_to_back(pkg, synth):
+    """Two handles on device 0 (the worker's default: --contexts 2) share the device's scratch array and enqueue on their
+    own non-blocking streams.  Called one after the other with NO sync in between, the library has to order the two passes
+    on the device; each result must still equal the allocating entry point's, bit for bit."""
+    import torch
+    torch.cuda.init()
+    cfg = synth.SMALL
+    va = _load(pkg, synth, "SMALL", 8)
+    vb = _load(pkg, synth, "SMALL", 8)
+    stride = (va.unit_samples + 63) // 64 * 64
+    L = va.unit_samples
+    for rep in range(4):
+        ca = _units(synth, cfg, 9, 8, 100 + 10 * rep)
+        cb = _units(synth, cfg, 7, 8, 300 + 10 * rep, tail=3)
+        d_ca = torch.from_numpy(ca).cuda()
+        d_cb = torch.from_numpy(cb).cuda()
+        ref_a = torch.zeros((9, stride), dtype=torch.float32, device="cuda")
+        ref_b = torch.zeros((7, stride), dtype=torch.float32, device="cuda")
+        got_a = torch.full((9, stride), -7.0, dtype=torch.float32, device="cuda")
+        got_b = torch.full((7, stride), -7.0, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        va.decode_units_device(d_ca.data_ptr(), 9, ref_a.data_ptr(), stride)
+        vb.decode_units_device(d_cb.data_ptr(), 7, ref_b.data_ptr(), stride)
+        va.sync()
+        vb.sync()
+        # back to back, alternating handles, nothing waits on the host in between
+        va.decode_units_device_noalloc(d_ca.data_ptr(), 9, got_a.data_ptr(), stride)
+        vb.decode_units_device_noalloc(d_cb.data_ptr(), 7, got_b.data_ptr(), stride)
+        va.decode_units_device_noalloc(d_ca.data_ptr(), 9, got_a.data_ptr(), stride)
+        vb.decode_units_device_noalloc(d_cb.data_ptr(), 7, got_b.data_ptr(), stride)
+        va.sync()
+        vb.sync()
+        for ref, got in ((ref_a, got_a), (ref_b, got_b)):
+            r, g = ref.cpu().numpy()[:, :L], got.cpu().numpy()[:, :L]
+            assert np.isfinite(r).all() and r.std() > 0
+            assert np.array_equal(r.view(np.uint32), g.view(np.uint32)), rep
+    va.close()
+    vb.close()
