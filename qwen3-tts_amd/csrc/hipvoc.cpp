@@ -29,6 +29,7 @@
 #include "kernels.h"
 #include "safetensors.hpp"
 #include "scratch.h"
+#include <dlfcn.h>
 
 namespace hipvoc {
 
@@ -1154,6 +1155,39 @@ static Plan *get_plan(Ctx *c, int G, int T, bool debug = false, bool in_scratch 
     return raw;
 }
 
+// roctx ranges (tracing): with HIPVOC_ROCTX=1 (or HIPVOC_PROFILE=1) every plan step is bracketed by
+// roctxRangePushA("<step>|<kernel>") / roctxRangePop, and a pass by "hipvoc_pass G=<units>", so that `rocprofv3 --marker-trace
+// --kernel-trace` on the worker (or on a host that embeds the library) shows named launches.  The roctx library is looked up
+// with dlopen at first use -- no link-time dependency, so the static-link recipe (build.rs) is unchanged -- and the ranges
+// cost nothing when neither variable is set or the library is absent.
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        const char *a = getenv("HIPVOC_ROCTX"), *b = getenv("HIPVOC_PROFILE");
+        if (!((a && atoi(a)) || (b && atoi(b)))) return;
+        for (const char *lib : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+            if (void *h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL)) {
+                push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+                pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+                if (push && pop) return;
+                push = nullptr; pop = nullptr;
+            }
+        }
+    }
+};
+static const Roctx &roctx() {
+    static const Roctx r;
+    return r;
+}
+struct RoctxRange {
+    bool on;
+    explicit RoctxRange(const char *name) : on(roctx().push != nullptr) { if (on) roctx().push(name); }
+    ~RoctxRange() { if (on) roctx().pop(); }
+    RoctxRange(const RoctxRange &) = delete;
+    RoctxRange &operator=(const RoctxRange &) = delete;
+};
+
 // Runs the plan for one group.  stop_stage >= 0: stop after the step that completes it.
 static int run_plan(Ctx *c, Plan *p, const long long *d_codes, float *d_out, long out_stride, int stop_stage,
                     const Step **stopped) {
@@ -1170,9 +1204,15 @@ static int run_plan(Ctx *c, Plan *p, const long long *d_codes, float *d_out, lon
     // rows (rocprofv3 counter CSVs are in dispatch order) to steps: "HIPVOC_STEP <index> <step> <kernel> <macs> <bytes>"
     static const bool trace_steps = getenv("HIPVOC_TRACE_STEPS") != nullptr;
     size_t ran = 0;
+    char pass_name[48];
+    if (roctx().push) snprintf(pass_name, sizeof pass_name, "hipvoc_pass G=%d T=%d", p->G, p->T);
+    RoctxRange pass_range(roctx().push ? pass_name : "");
     for (size_t i = 0; i < p->steps.size(); i++) {
         const Step &s = p->steps[i];
         if (trace_steps) fprintf(stderr, "HIPVOC_STEP %zu %s %s %.0f %.0f\n", i, s.name, s.kernel, s.macs, s.bytes);
+        char rname[160];
+        if (roctx().push) snprintf(rname, sizeof rname, "%s|%s", s.name, s.kernel);
+        RoctxRange step_range(roctx().push ? rname : "");
         hipError_t e = s.run(c->stream);
         if (e != hipSuccess) {
             c->err = fmt("launch of %s failed: %s", s.name, hipGetErrorString(e));

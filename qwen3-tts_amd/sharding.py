@@ -69,6 +69,11 @@ class UnitGather:
 
     def gather(self, local, n_local: int):
         """local: [>= n_local, stride] tensor holding this rank's decoded units (complete on its device)."""
+        if n_local == self.max_units and local.is_contiguous() and local.shape[1] == self.pad.shape[1]:
+            # a full-sized shard is already the buffer the collective wants: no staging copy (a rank with the largest
+            # share -- every rank when the units divide evenly -- sends its decode output as it lies)
+            self.dist.gather(local[:n_local], self.parts, dst=0)
+            return
         self.pad[:n_local] = local[:n_local]
         self.dist.gather(self.pad, self.parts, dst=0)
 

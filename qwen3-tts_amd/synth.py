@@ -76,12 +76,32 @@ ODD = DecoderConfig(codebook_size=50, codebook_dim=40, latent_dim=72, hidden_siz
                     sliding_window=5)
 
 
-def make_weights(cfg: DecoderConfig = FULL, seed: int = 0) -> Dict[str, np.ndarray]:
-    rng = np.random.default_rng(seed)
+FAMILIES = ("gauss", "hostile")
+HOSTILE_FINAL_GAIN = 0.08
+
+
+def make_weights(cfg: DecoderConfig = FULL, seed: int = 0, family: str = "gauss") -> Dict[str, np.ndarray]:
+    """family "gauss": the default above.  family "hostile": the statistics that eat the margin of reduced-product
+    arithmetic (Winograd F(2,7) / F(3,2) with points +-2, +-1/2; the bf16x3 split's dropped mid*mid term) -- heavy-tailed
+    conv weights (Student-t, 4 degrees of freedom, same variance), SnakeBeta alpha and beta uniform in [-1, 1.5] (e^alpha up
+    to 4.5: many periods of sin^2 per unit of x), O(1) per-channel DC offsets on the residual stream ahead of every k = 7
+    conv (biases of the trans-convs and of the 1x1 convs), per-channel gains spread over 1/8 .. 8 on the trans-conv outputs,
+    LayerScale / ConvNeXt gamma up to 1.  Used by tests/test_gpu_margin.py; the oracle is the checker."""
+    if family not in FAMILIES:
+        raise ValueError(f"family {family!r}: expected one of {FAMILIES}")
+    hostile = family == "hostile"
+    rng = np.random.default_rng(seed if not hostile else seed + 104729)
     W: Dict[str, np.ndarray] = {}
 
     def normal(shape, std):
         return (rng.standard_normal(shape, dtype=np.float32) * np.float32(std)).astype(np.float32)
+
+    def heavy(shape, std):
+        """conv / linear weights: normal, or (hostile) Student-t with 4 degrees of freedom scaled to the same variance"""
+        if not hostile:
+            return normal(shape, std)
+        t = rng.standard_t(4, size=shape).astype(np.float32) * np.float32(2.0 ** -0.5)
+        return (t * np.float32(std)).astype(np.float32)
 
     def uniform(shape, lo, hi):
         return rng.uniform(lo, hi, size=shape).astype(np.float32)
@@ -104,14 +124,24 @@ def make_weights(cfg: DecoderConfig = FULL, seed: int = 0) -> Dict[str, np.ndarr
         W[f"decoder.quantizer.{g}.input_proj.weight"] = normal((half, cfg.codebook_dim, 1), cfg.codebook_dim ** -0.5)
         W[f"decoder.quantizer.{g}.output_proj.weight"] = normal((cfg.codebook_dim, half, 1), (2 * half) ** -0.5)
 
-    def conv(prefix, cout, cin, k, gain=1.0):
-        W[prefix + ".weight"] = normal((cout, cin, k), gain * (cin * k) ** -0.5)
-        W[prefix + ".bias"] = normal((cout,), 0.02)
+    def conv(prefix, cout, cin, k, gain=1.0, dc=0.0):
+        W[prefix + ".weight"] = heavy((cout, cin, k), gain * (cin * k) ** -0.5)
+        W[prefix + ".bias"] = normal((cout,), 0.02) + (uniform((cout,), -dc, dc) if dc else np.float32(0))
 
     def linear(prefix, cout, cin, bias=True, gain=1.0):
-        W[prefix + ".weight"] = normal((cout, cin), gain * cin ** -0.5)
+        W[prefix + ".weight"] = heavy((cout, cin), gain * cin ** -0.5)
         if bias:
             W[prefix + ".bias"] = normal((cout,), 0.02)
+
+    def snake(prefix, c):
+        if hostile:
+            W[prefix + "alpha"] = uniform((c,), -1.0, 1.5)
+            W[prefix + "beta"] = uniform((c,), -1.0, 1.5)
+        else:
+            W[prefix + "alpha"] = normal((c,), 0.3)
+            W[prefix + "beta"] = normal((c,), 0.3)
+
+    ls_lo, ls_hi = (0.3, 1.0) if hostile else (0.05, 0.4)
 
     conv("decoder.pre_conv.conv", cfg.latent_dim, cfg.codebook_dim, 3)
     pt = "decoder.pre_transformer"
@@ -127,8 +157,8 @@ def make_weights(cfg: DecoderConfig = FULL, seed: int = 0) -> Dict[str, np.ndarr
         linear(f"{p}.mlp.down_proj", cfg.hidden_size, cfg.intermediate_size, bias=False)
         W[f"{p}.input_layernorm.weight"] = (1.0 + normal((cfg.hidden_size,), 0.1)).astype(np.float32)
         W[f"{p}.post_attention_layernorm.weight"] = (1.0 + normal((cfg.hidden_size,), 0.1)).astype(np.float32)
-        W[f"{p}.self_attn_layer_scale.scale"] = uniform((cfg.hidden_size,), 0.05, 0.4)
-        W[f"{p}.mlp_layer_scale.scale"] = uniform((cfg.hidden_size,), 0.05, 0.4)
+        W[f"{p}.self_attn_layer_scale.scale"] = uniform((cfg.hidden_size,), ls_lo, ls_hi)
+        W[f"{p}.mlp_layer_scale.scale"] = uniform((cfg.hidden_size,), ls_lo, ls_hi)
     W[pt + ".norm.weight"] = (1.0 + normal((cfg.hidden_size,), 0.1)).astype(np.float32)
     linear(pt + ".output_proj", cfg.latent_dim, cfg.hidden_size)
 
@@ -143,30 +173,32 @@ def make_weights(cfg: DecoderConfig = FULL, seed: int = 0) -> Dict[str, np.ndarr
         W[p + ".1.norm.bias"] = normal((C,), 0.05)
         linear(p + ".1.pwconv1", 4 * C, C)
         linear(p + ".1.pwconv2", C, 4 * C)
-        W[p + ".1.gamma"] = uniform((C,), 0.05, 0.4)
+        W[p + ".1.gamma"] = uniform((C,), ls_lo, ls_hi)
 
     conv("decoder.decoder.0.conv", cfg.decoder_dim, C, 7)
     cin = cfg.decoder_dim
     for b, r in enumerate(cfg.upsample_rates):
         p = f"decoder.decoder.{b + 1}.block"
         cout = cin // 2
-        W[p + ".0.alpha"] = normal((cin,), 0.3)
-        W[p + ".0.beta"] = normal((cin,), 0.3)
-        W[p + ".1.conv.weight"] = normal((cin, cout, 2 * r), 0.7 * (2 * cin) ** -0.5)
-        W[p + ".1.conv.bias"] = normal((cout,), 0.02)
+        snake(p + ".0.", cin)
+        tw = heavy((cin, cout, 2 * r), 0.7 * (2 * cin) ** -0.5)
+        if hostile:      # per-output-channel gains over 1/8 .. 8 (log-uniform), renormalised to the same mean square
+            g = np.exp(rng.uniform(np.log(0.125), np.log(8.0), size=(cout,))).astype(np.float32)
+            g /= np.sqrt(np.mean(g * g, dtype=np.float64)).astype(np.float32)
+            tw = (tw * g[None, :, None]).astype(np.float32)
+        W[p + ".1.conv.weight"] = tw
+        W[p + ".1.conv.bias"] = normal((cout,), 0.02) + (uniform((cout,), -1.0, 1.0) if hostile else np.float32(0))
         for u in range(3):
             q = f"{p}.{u + 2}"
-            W[q + ".act1.alpha"] = normal((cout,), 0.3)
-            W[q + ".act1.beta"] = normal((cout,), 0.3)
+            snake(q + ".act1.", cout)
             conv(q + ".conv1.conv", cout, cout, 7, gain=0.8)
-            W[q + ".act2.alpha"] = normal((cout,), 0.3)
-            W[q + ".act2.beta"] = normal((cout,), 0.3)
-            conv(q + ".conv2.conv", cout, cout, 1, gain=0.35)
+            snake(q + ".act2.", cout)
+            conv(q + ".conv2.conv", cout, cout, 1, gain=0.35, dc=0.5 if hostile else 0.0)
         cin = cout
     nb = len(cfg.upsample_rates)
-    W[f"decoder.decoder.{nb + 1}.alpha"] = normal((cin,), 0.3)
-    W[f"decoder.decoder.{nb + 1}.beta"] = normal((cin,), 0.3)
-    conv(f"decoder.decoder.{nb + 2}.conv", 1, cin, 7, gain=0.12)
+    snake(f"decoder.decoder.{nb + 1}.", cin)
+    # (hostile: the activations ahead of the final conv are several times larger; keep the waveform inside the clamp)
+    conv(f"decoder.decoder.{nb + 2}.conv", 1, cin, 7, gain=0.12 if not hostile else HOSTILE_FINAL_GAIN)
     return W
 
 

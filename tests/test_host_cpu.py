@@ -103,6 +103,14 @@ dist.destroy_process_group()
 """
 
 
+def _free_port():
+    """A port the kernel just handed out (bind to 0), as bench.py's launcher does: two suites on one box do not collide."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def test_longform_sharding_world2_gloo(tmp_path):
     """The N>1 path (contiguous unit ranges per rank + gather on rank 0) on CPU with gloo; the decode
     function is the oracle here, the partition/stitch logic is the product's."""
@@ -110,7 +118,7 @@ def test_longform_sharding_world2_gloo(tmp_path):
     script.write_text(WORKER.format(root=ROOT))
     env = dict(os.environ, OMP_NUM_THREADS="2")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)],
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "OK 20010" in r.stdout        # 2 full units of out_len(4)=7125 + a 3-frame tail of 3*1920
@@ -152,7 +160,7 @@ def test_encoder_clip_sharding_world2_gloo(tmp_path):
     script.write_text(ENC_WORKER.format(root=ROOT))
     env = dict(os.environ, OMP_NUM_THREADS="2")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29537", str(script)],
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)],
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "OK 15" in r.stdout          # 3 + 5 + 2 + 4 + 1 frames
