@@ -76,20 +76,34 @@ ODD = DecoderConfig(codebook_size=50, codebook_dim=40, latent_dim=72, hidden_siz
                     sliding_window=5)
 
 
-FAMILIES = ("gauss", "hostile")
-HOSTILE_FINAL_GAIN = 0.08
+# Weight families beside the default: knobs of make_weights.  heavy: Student-t(4) conv / linear weights; ab: range of the
+# SnakeBeta alpha and beta (uniform); dc / dc2: per-channel DC offsets on the residual stream (trans-conv bias / 1x1-conv
+# bias); spread: per-channel gains of the trans-conv outputs, log-uniform over 1/spread .. spread; ls: LayerScale and
+# ConvNeXt gamma range; final_gain: of the last conv (keeps the waveform inside the clamp).
+FAMILY_KNOBS = {
+    "gauss": None,
+    # what VERDICT r2 asked for.  Measured (tests/test_gpu_margin.py): this network is ILL-CONDITIONED -- perturbing its
+    # weights by half an fp32 ulp moves the waveform by 1.1e-3 / 59.6 dB (the default family: 4.4e-6 / 104 dB), so no fp32
+    # implementation can hold the 1e-3 / 60 dB gates on it against another; it is judged against that floor instead.
+    "hostile": dict(heavy=True, ab=(-1.0, 1.5), dc=1.0, dc2=0.5, spread=8.0, ls=(0.3, 1.0), final_gain=0.08),
+    # the same ingredients at the strength where the network's own half-ulp sensitivity stays ~10x the default family's:
+    # the absolute gates apply
+    "stress": dict(heavy=True, ab=(-1.0, 0.9), dc=1.0, dc2=0.5, spread=8.0, ls=(0.3, 1.0), final_gain=0.1),
+}
+FAMILIES = tuple(FAMILY_KNOBS)
 
 
 def make_weights(cfg: DecoderConfig = FULL, seed: int = 0, family: str = "gauss") -> Dict[str, np.ndarray]:
-    """family "gauss": the default above.  family "hostile": the statistics that eat the margin of reduced-product
-    arithmetic (Winograd F(2,7) / F(3,2) with points +-2, +-1/2; the bf16x3 split's dropped mid*mid term) -- heavy-tailed
-    conv weights (Student-t, 4 degrees of freedom, same variance), SnakeBeta alpha and beta uniform in [-1, 1.5] (e^alpha up
-    to 4.5: many periods of sin^2 per unit of x), O(1) per-channel DC offsets on the residual stream ahead of every k = 7
-    conv (biases of the trans-convs and of the 1x1 convs), per-channel gains spread over 1/8 .. 8 on the trans-conv outputs,
-    LayerScale / ConvNeXt gamma up to 1.  Used by tests/test_gpu_margin.py; the oracle is the checker."""
+    """family "gauss": the default above.  Families "hostile" / "stress" (FAMILY_KNOBS): the statistics that eat the margin
+    of reduced-product arithmetic (Winograd F(2,7) / F(3,2) with points +-2, +-1/2; the bf16x3 split's dropped mid*mid term)
+    -- heavy-tailed conv weights (Student-t, 4 degrees of freedom, same variance), SnakeBeta alpha and beta uniform over a
+    range reaching e^alpha = 4.5 (many periods of sin^2 per unit of x), O(1) per-channel DC offsets on the residual stream
+    ahead of every k = 7 conv (biases of the trans-convs and of the 1x1 convs), per-channel gains spread over 1/8 .. 8 on the
+    trans-conv outputs, LayerScale / ConvNeXt gamma up to 1.  Used by tests/test_gpu_margin.py; the oracle is the checker."""
     if family not in FAMILIES:
         raise ValueError(f"family {family!r}: expected one of {FAMILIES}")
-    hostile = family == "hostile"
+    knobs = FAMILY_KNOBS[family]
+    hostile = knobs is not None
     rng = np.random.default_rng(seed if not hostile else seed + 104729)
     W: Dict[str, np.ndarray] = {}
 
@@ -98,7 +112,7 @@ def make_weights(cfg: DecoderConfig = FULL, seed: int = 0, family: str = "gauss"
 
     def heavy(shape, std):
         """conv / linear weights: normal, or (hostile) Student-t with 4 degrees of freedom scaled to the same variance"""
-        if not hostile:
+        if not (hostile and knobs["heavy"]):
             return normal(shape, std)
         t = rng.standard_t(4, size=shape).astype(np.float32) * np.float32(2.0 ** -0.5)
         return (t * np.float32(std)).astype(np.float32)
@@ -135,13 +149,13 @@ def make_weights(cfg: DecoderConfig = FULL, seed: int = 0, family: str = "gauss"
 
     def snake(prefix, c):
         if hostile:
-            W[prefix + "alpha"] = uniform((c,), -1.0, 1.5)
-            W[prefix + "beta"] = uniform((c,), -1.0, 1.5)
+            W[prefix + "alpha"] = uniform((c,), *knobs["ab"])
+            W[prefix + "beta"] = uniform((c,), *knobs["ab"])
         else:
             W[prefix + "alpha"] = normal((c,), 0.3)
             W[prefix + "beta"] = normal((c,), 0.3)
 
-    ls_lo, ls_hi = (0.3, 1.0) if hostile else (0.05, 0.4)
+    ls_lo, ls_hi = knobs["ls"] if hostile else (0.05, 0.4)
 
     conv("decoder.pre_conv.conv", cfg.latent_dim, cfg.codebook_dim, 3)
     pt = "decoder.pre_transformer"
@@ -182,23 +196,23 @@ def make_weights(cfg: DecoderConfig = FULL, seed: int = 0, family: str = "gauss"
         cout = cin // 2
         snake(p + ".0.", cin)
         tw = heavy((cin, cout, 2 * r), 0.7 * (2 * cin) ** -0.5)
-        if hostile:      # per-output-channel gains over 1/8 .. 8 (log-uniform), renormalised to the same mean square
-            g = np.exp(rng.uniform(np.log(0.125), np.log(8.0), size=(cout,))).astype(np.float32)
+        if hostile:      # per-output-channel gains over 1/spread .. spread (log-uniform), renormalised to the same mean square
+            g = np.exp(rng.uniform(-np.log(knobs["spread"]), np.log(knobs["spread"]), size=(cout,))).astype(np.float32)
             g /= np.sqrt(np.mean(g * g, dtype=np.float64)).astype(np.float32)
             tw = (tw * g[None, :, None]).astype(np.float32)
         W[p + ".1.conv.weight"] = tw
-        W[p + ".1.conv.bias"] = normal((cout,), 0.02) + (uniform((cout,), -1.0, 1.0) if hostile else np.float32(0))
+        W[p + ".1.conv.bias"] = normal((cout,), 0.02) + (uniform((cout,), -knobs["dc"], knobs["dc"]) if hostile else np.float32(0))
         for u in range(3):
             q = f"{p}.{u + 2}"
             snake(q + ".act1.", cout)
             conv(q + ".conv1.conv", cout, cout, 7, gain=0.8)
             snake(q + ".act2.", cout)
-            conv(q + ".conv2.conv", cout, cout, 1, gain=0.35, dc=0.5 if hostile else 0.0)
+            conv(q + ".conv2.conv", cout, cout, 1, gain=0.35, dc=knobs["dc2"] if hostile else 0.0)
         cin = cout
     nb = len(cfg.upsample_rates)
     snake(f"decoder.decoder.{nb + 1}.", cin)
     # (hostile: the activations ahead of the final conv are several times larger; keep the waveform inside the clamp)
-    conv(f"decoder.decoder.{nb + 2}.conv", 1, cin, 7, gain=0.12 if not hostile else HOSTILE_FINAL_GAIN)
+    conv(f"decoder.decoder.{nb + 2}.conv", 1, cin, 7, gain=0.12 if not hostile else knobs["final_gain"])
     return W
 
 
