@@ -131,6 +131,7 @@ struct Ctx {
     bool wino_tconv = true;    // fp32 mode: the decoder blocks' transposed convs by F(3,2) (HIPVOC_WINO_TCONV=0: direct)
     bool wino_unfuse = true;   // blocks whose residual units could be fused run un-fused when their conv7 has a Winograd form (HIPVOC_WINO_UNFUSE=0)
     bool wino_unit = true;     // fp32 mode: residual units of a 96-channel block as ONE Winograd kernel each (wino_ps_kernel<D,3,true>; HIPVOC_WINO_UNIT=0: the fused direct kernel)
+    bool blk3 = true;          // bf16 mode: the three residual units of a 96-channel block as ONE launch (resblock3_bf16_kernel; HIPVOC_BLK3=0: one launch per unit)
     bool wino = true;          // fp32 mode: k = 7 convs of the un-fused residual units by Winograd F(2,7) (HIPVOC_WINO=0: direct)
     bool trim_right = false;   // trans-conv trim policy (metadata transconv_trim_right_only=1): keep L*r samples instead of (L-1)*r
     bool is_encoder = false;   // handle made by hipvoc_enc_load (encoder.inc.cpp): the vocoder entry points refuse it
@@ -157,7 +158,7 @@ struct Ctx {
     struct Up { Gemm tc, pw1, pw2; float *dw_w, *dw_b, *ln_w, *ln_b, *gamma; int K; };
     std::vector<Up> ups;
     struct Res { Snake s1, s2; Gemm c1, c2; };
-    struct Block { Snake s; Gemm tc; Res res[3]; };
+    struct Block { Snake s; Gemm tc; Res res[3]; unsigned short *ws3 = nullptr; };   // ws3: bf16 mode, weight stream of resblock3_bf16_kernel
     std::vector<Block> blocks;
     Snake fin_snake;
     float *fin_w_raw = nullptr;   // [C][K] for the dedicated final-stage kernel
@@ -648,6 +649,41 @@ static bool load_model(Ctx *c, const char *path, std::string &err) {
             b.res[u].s2 = L.snake(q + "act2.", Co);
             b.res[u].c2 = L.conv({q + "conv2.conv.weight"}, q + "conv2.conv.bias", 1);
         }
+        // bf16 mode, 96-channel block: the units' weights once more as the cyclic slot stream of resblock3_bf16_kernel
+        // (kernels_blk3.hip): per unit the 21 (channel block, tap) tiles of the conv7 in accumulation order, then the three
+        // output tiles of the 1x1 conv -- device-to-device copies out of the tensors the per-unit kernels use
+        if (L.ok && c->bf16 && !c->split3 && resblock3_bf16_supported(Co, dils)) {
+            bool fits = true;
+            for (int u = 0; u < 3; u++) {
+                const Gemm &c1 = b.res[u].c1, &c2 = b.res[u].c2;
+                fits = fits && c1.wb && c2.wb2 && c1.ntaps == 7 && c1.Cin == Co && c1.N == Co && c1.NP == Co && c2.NP == Co && c1.bias && c2.bias &&
+                       c1.step == dils[u] && c1.shift0 == -6 * dils[u];
+            }
+            if (fits) {
+                const size_t slot = resblock3_bf16_slot_bytes(), total = resblock3_bf16_stream_bytes();
+                void *ws = nullptr;
+                hipError_t e = hipMalloc(&ws, total + 1024);
+                if (e == hipSuccess) e = hipMemset(ws, 0, total + 1024);
+                const int ncb = Co / 32;
+                for (int u = 0; u < 3 && e == hipSuccess; u++) {
+                    char *dst = static_cast<char *>(ws) + (size_t)u * 24 * slot;
+                    for (int st = 0; st < 21 && e == hipSuccess; st++) {
+                        const int cb = st / 7, tap = st % 7;
+                        e = hipMemcpy(dst + (size_t)st * slot, reinterpret_cast<const char *>(b.res[u].c1.wb) + (size_t)(tap * ncb + cb) * slot, slot,
+                                      hipMemcpyDeviceToDevice);
+                    }
+                    if (e == hipSuccess)
+                        e = hipMemcpy(dst + (size_t)21 * slot, b.res[u].c2.wb2, 3 * slot, hipMemcpyDeviceToDevice);
+                }
+                if (e != hipSuccess) {
+                    if (ws) (void)hipFree(ws);
+                    err = std::string("weight stream of the fused block: ") + hipGetErrorString(e);
+                    return false;
+                }
+                c->dev_allocs.push_back(ws);
+                b.ws3 = static_cast<unsigned short *>(ws);
+            }
+        }
         c->rates.push_back(r);
         c->blocks.push_back(b);
         C = Co;
@@ -1000,6 +1036,7 @@ static std::unique_ptr<Plan> build_plan(Ctx *c, int G, int T, bool debug, char *
         static const char *c7n[] = {"b0_conv7", "b1_conv7", "b2_conv7", "b3_conv7", "bN_conv7"};
         static const char *run[] = {"b0_resunit", "b1_resunit", "b2_resunit", "b3_resunit", "bN_resunit"};
         static const char *c1n[] = {"b0_conv1", "b1_conv1", "b2_conv1", "b3_conv1", "bN_conv1"};
+        static const char *rbn[] = {"b0_resblock", "b1_resblock", "b2_resblock", "b3_resblock", "bN_resblock"};
         for (size_t bi = 0; bi < c->blocks.size(); bi++) {
             const Ctx::Block &blk = c->blocks[bi];
             const int r = c->rates[bi];
@@ -1013,6 +1050,34 @@ static std::unique_ptr<Plan> build_plan(Ctx *c, int G, int T, bool debug, char *
             pc ^= 1;
             L = L2; Lp = Lp2; C = blk.tc.N / r;
             b.mark(st++, cur, C, L, Lp);
+            if (c->blk3 && blk.ws3 && fused_blk && !debug) {
+                // the block's three residual units in one launch that walks along time (kernels_blk3.hip); bit-identical to
+                // the three launches below
+                const bool lastb = bi + 1 == c->blocks.size();
+                ResBlock3Args a{};
+                a.xb = pk[pc]; a.x = cur; a.ws = blk.ws3;
+                a.y = lastb ? t1 : nullptr;
+                a.yb = lastb ? nullptr : pk[pc ^ 1];
+                for (int u = 0; u < 3; u++) {
+                    const Ctx::Res &ru = blk.res[u];
+                    const Snake *next = u < 2 ? &blk.res[u + 1].s1 : (lastb ? fin_post : &c->blocks[bi + 1].s);
+                    a.bias1[u] = ru.c1.bias; a.sn2_a[u] = ru.s2.ea; a.sn2_ib[u] = ru.s2.ib; a.bias2[u] = ru.c2.bias;
+                    a.psn_a[u] = next ? next->ea : nullptr; a.psn_ib[u] = next ? next->ib : nullptr;
+                    a.dil[u] = ru.c1.step;
+                }
+                a.G = G; a.L = L; a.us = Lp; a.cs = (long)G * Lp;
+                double macs = 0;
+                for (int u = 0; u < 3; u++) macs += (double)G * L * blk.res[u].c1.N * ((double)blk.res[u].c1.Cin * blk.res[u].c1.ntaps + blk.res[u].c2.Cin);
+                b.add(rbn[ni], "resblock3_bf16_kernel", macs, [a](hipStream_t s) { return launch_resblock3_bf16(a, s); });
+                {
+                    const double el = (double)C * G * L;             // packed operand + fp32 residual in, fp32 or packed out
+                    b.p->steps.back().bytes = el * (2 + 4) + el * (lastb ? 4 : 2);
+                }
+                if (lastb) std::swap(cur, t1); else pc ^= 1;
+                if (lastb) b.mark(st + 2, cur, C, L, Lp);
+                st += 3;
+                continue;
+            }
             for (int u = 0; u < 3; u++) {
                 const Ctx::Res &ru = blk.res[u];
                 const bool last = u == 2 && bi + 1 == c->blocks.size();      // feeds the final conv: fp32 only
@@ -1489,6 +1554,7 @@ static void *load_impl(const char *weights_path, int device_id, int dtype, int u
     if (const char *ps = getenv("HIPVOC_PHASE_MAJOR")) c->phase_major = atoi(ps) != 0;
     if (const char *ps = getenv("HIPVOC_TCONV_OI")) c->tconv_oi = atoi(ps) != 0;
     if (const char *ps = getenv("HIPVOC_WINO")) c->wino = atoi(ps) != 0;
+    if (const char *ps = getenv("HIPVOC_BLK3")) c->blk3 = atoi(ps) != 0;
     if (const char *ps = getenv("HIPVOC_WINO_UNFUSE")) c->wino_unfuse = atoi(ps) != 0;
     if (const char *ps = getenv("HIPVOC_WINO_TCONV")) c->wino_tconv = atoi(ps) != 0;
     if (const char *ps = getenv("HIPVOC_WINO_UNIT")) c->wino_unit = atoi(ps) != 0;

@@ -115,6 +115,26 @@ int conv_gemm_launch_tn(const ConvGemmArgs &a);                     // row-tile 
 const char *conv_gemm_kernel_name(const ConvGemmArgs &a);
 size_t conv_gemm_lds_bytes(const ConvGemmArgs &a);
 
+// kernels_blk3.hip (bf16 mode): the three residual units of a 96-channel decoder block in ONE launch that walks along time
+// (dilations 1, 3, 9); bit-identical to three launches of the fused per-unit kernel.
+struct ResBlock3Args {
+    const unsigned short *xb;      // packed activated operand of unit 0, snake_s1(x): [C/8][G][Lp] 16-byte elements
+    const float *x;                // the raw residual stream [C][G][Lp]
+    float *y;                      // fp32 output (the raw value when yb is given, else psn[2](out) if psn[2] is given), or null with yb
+    unsigned short *yb;            // optional packed output psn[2](out)
+    const unsigned short *ws;      // the block's weight stream: [3 units][24 slots][6 KB] (hipvoc.cpp: blk3_stream)
+    const float *bias1[3], *sn2_a[3], *sn2_ib[3], *bias2[3];
+    const float *psn_a[3], *psn_ib[3];   // activation applied to a unit's output: the next unit's, then what follows the block (may be null)
+    int dil[3];
+    int G, L;                      // units, positions per unit
+    long us, cs;                   // unit / channel strides in floats (= in 16-byte elements of the packed tensors)
+    int span_tiles, spans_per_unit;      // set by the launcher
+};
+bool resblock3_bf16_supported(int C, const int *dil);
+size_t resblock3_bf16_stream_bytes();
+size_t resblock3_bf16_slot_bytes();
+hipError_t launch_resblock3_bf16(const ResBlock3Args &a, hipStream_t s);
+
 struct RvqArgs {
     const long long *codes;   // [G][T][nq]
     const float *embed;       // [nq][cb_size][D]  (embed_sum / clamp(usage,1e-5), done on the host)

@@ -205,3 +205,39 @@ def test_bf16_gemm1_bitwise(pkg, synth, cfg_name, unit, frames, monkeypatch):
             assert used == (wgs != "0"), (wgs, name, sorted(v.last_profile()))
         del v
     assert outs[0].size and np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+
+
+@pytest.mark.parametrize("unit,frames,n_seq", [(64, 125, 1), (7, 33, 3), (64, 64, 9)])
+def test_bf16_block3_walk_equals_three_unit_launches_bitwise(pkg, synth, unit, frames, n_seq, monkeypatch):
+    """bf16 mode, block 3 (96 channels): resblock3_bf16_kernel runs the block's three residual units in ONE launch that
+    walks along time (kernels_blk3.hip) -- per output element the same MFMA chains, SnakeBeta evaluations, roundings and
+    residual adds as three launches of the fused per-unit kernel (HIPVOC_BLK3=0), so the waveforms must be identical bit
+    for bit: whatever the number of spans a unit is cut into (a span that does not start at position 0 rebuilds its
+    history from the tile to its left), for a lone utterance, short units and a pass of several sequences."""
+    cfg = synth.FULL
+    path = os.path.join(tempfile.gettempdir(), "hipvoc_test_FULL_0.safetensors")
+    if not os.path.exists(path):
+        synth.save_safetensors(path, weights_for(synth, "FULL", 0), cfg.metadata())
+    seqs = [synth.make_codes(frames, 77 + i, cfg) for i in range(n_seq)]
+    monkeypatch.setenv("HIPVOC_BLK3", "0")
+    ref_v = pkg.HipVocoder.load(path, device=0, unit_frames=unit, dtype=BF16)
+    ref_v.set_profile(True)
+    ref = ref_v.synthesize_batch(seqs)
+    assert not any("resblock3" in k for k in ref_v.last_profile())
+    del ref_v
+    monkeypatch.setenv("HIPVOC_BLK3", "1")
+    v = pkg.HipVocoder.load(path, device=0, unit_frames=unit, dtype=BF16)
+    for spans in (None, "1", "2", "7", "100000"):
+        if spans is None:
+            monkeypatch.delenv("HIPVOC_BLK3_SPANS", raising=False)
+        else:
+            monkeypatch.setenv("HIPVOC_BLK3_SPANS", spans)       # read at every launch
+        v.set_profile(spans is None)
+        got = v.synthesize_batch(seqs)
+        if spans is None:
+            assert any("resblock3_bf16_kernel" in k for k in v.last_profile()), sorted(v.last_profile())
+            assert not any("b3_resunit" in k for k in v.last_profile())
+        for a, b in zip(ref, got):
+            assert a.size == b.size and a.size > 0
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (spans, float(np.abs(a - b).max()))
+    del v
