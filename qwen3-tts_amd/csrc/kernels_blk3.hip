@@ -31,6 +31,26 @@ namespace hipvoc {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void *b3_lptr_t;
+// LDS operand reads by 32-bit LDS address (generic-pointer arithmetic is 64-bit VALU work per read)
+typedef const __attribute__((address_space(3))) bf16x8 *b3_lds16_t;
+#ifndef B3_ABL
+#define B3_ABL 0
+#endif
+#ifndef B3_PF
+#define B3_PF 1          // k-steps the LDS operand reads run ahead of their MFMAs
+#endif
+#ifndef B3_SKEW
+#define B3_SKEW 0        // s_sleep argument (x 64 cycles) of waves 4-7 after every group barrier
+#endif
+__device__ __forceinline__ bf16x8 b3_lds16(unsigned addr) {
+#if B3_ABL & 32
+    bf16x8 v;
+    for (int j = 0; j < 8; j++) v[j] = (__bf16)(float)(addr & 7);
+    return v;
+#else
+    return *(b3_lds16_t)(size_t)addr;
+#endif
+}
 
 namespace blk3 {
 constexpr int C = 96, TN = 3, KG = 12;      // channels, 32-row tiles, k-groups of 8 channels
@@ -64,6 +84,43 @@ __device__ __forceinline__ void b3_dma16(const void *sbase, unsigned voff_bytes,
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(l), "v"(voff_bytes), "s"(bs) : "memory");
 }
 
+// SnakeBeta as this kernel evaluates it.  B3_ABL (timing-only experiments, tools/build_variant.sh; results are wrong with any
+// bit set): 1 = identity instead of SnakeBeta, 2 = the v_sin_f32 form, 4 = no residual loads / output stores, 8 = no weight
+// DMA after the first two groups, 16 = no MFMAs, 32 = no LDS operand reads, 64 = no group barriers.
+#ifndef B3_ABL
+#define B3_ABL 0
+#endif
+__device__ __forceinline__ f32x2 b3_snake2(f32x2 x, f32x2 ea, f32x2 ib) {
+#if B3_ABL & 1
+    return x + ib * ea * 1e-9f;
+#elif B3_ABL & 2
+    const f32x2 rev = (x * ea) * 0.15915494309189535f;
+    const float s0 = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(rev.x)), s1 = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(rev.y));
+    return fma2(ib, mk2(s0 * s0, s1 * s1), x);
+#else
+    return snake_beta2(x, ea, ib);
+#endif
+}
+
+// Top of a group: wait until at most N of this wave's vector-memory operations are outstanding (they complete in issue
+// order), then for its LDS writes, then for every wave.  N is the number of operations issued AFTER the DMA pieces of the
+// group about to be read (see the table in the kernel): those stay in flight across the barrier.
+template <int N>
+__device__ __forceinline__ void b3_wait_bar() {
+#if B3_ABL & 64
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(N) : "memory");
+#else
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+#endif
+}
+__device__ __forceinline__ f32x16 b3_mfma(bf16x8 a, bf16x8 b, f32x16 c) {
+#if B3_ABL & 16
+    c[0] += (float)a[0] + (float)b[0];
+    return c;
+#else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#endif
+}
 __global__ __launch_bounds__(blk3::NTH, 2) void resblock3_bf16_kernel(ResBlock3Args a) {
     using namespace blk3;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -71,7 +128,7 @@ __global__ __launch_bounds__(blk3::NTH, 2) void resblock3_bf16_kernel(ResBlock3A
     uint4 *Ab = reinterpret_cast<uint4 *>(smem + A_OFF);                // [12][XWB] activated tile, index 54 = the step's first position
     uint4 *Hs = reinterpret_cast<uint4 *>(smem + H_OFF);                // history stores, unit u at [12][6 d_u] from element hoff[u]
     const unsigned ring_lds = (unsigned)(size_t)(b3_lptr_t)(smem + R_OFF);
-    const unsigned char *Ring = smem + R_OFF;
+    const unsigned ab_lds = (unsigned)(size_t)(b3_lptr_t)(smem + A_OFF);
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l31 = lane & 31, h = lane >> 5;
@@ -103,6 +160,7 @@ __global__ __launch_bounds__(blk3::NTH, 2) void resblock3_bf16_kernel(ResBlock3A
     }
     const unsigned dma_voff = (unsigned)lane * 16u;
     auto dma_group = [&](int gi, int rbuf) {                            // group gi of the walk -> ring buffer rbuf
+        if ((B3_ABL & 8) && gi > 1) return;
         const unsigned char *src = reinterpret_cast<const unsigned char *>(a.ws) + (size_t)(gi % (3 * UGR)) * GRP;
 #pragma unroll
         for (int j = 0; j < 3; j++) {
@@ -144,11 +202,14 @@ __global__ __launch_bounds__(blk3::NTH, 2) void resblock3_bf16_kernel(ResBlock3A
 
     f32x16 y[TN];                                                       // the fp32 residual tile, rows (r&3) + 8(r>>2) + 4h of tile i
     int gi = 0;
+    int prev_stores = 0;                                                // stores this wave issued at the end of the previous step
     for (int step = first; step < ntiles; step++) {
         const int t0 = (tile0 + step) * BM;
         const int m = t0 + wave * 32 + l31;
         const bool stored = step >= 0;
         const bool has_next = step + 1 < ntiles;
+        // (wave-uniform) this wave stores its part of the step: then all its 48 store instructions are issued, under a lane mask
+        const bool wave_stores = stored && t0 + wave * 32 < a.L;
         for (int u = 0; u < 3; u++) {
             const int d = u == 0 ? d0 : (u == 1 ? d1 : d2);
             const float *P1 = Pm + u * 6 * C;
@@ -158,157 +219,29 @@ __global__ __launch_bounds__(blk3::NTH, 2) void resblock3_bf16_kernel(ResBlock3A
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[i][r] = 0.0f;
             bf16x8 hb[TN][2];
-            const uint4 *xsb = Ab + HMAX + wave * 32 + l31 - 6 * d;    // tap t of this lane's position: + t d
-#pragma unroll
-            for (int g = 0; g < UGR; g++, gi++) {
-                // every wave's pieces of the groups in flight have landed, its LDS writes are done; then: all of them
-                asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                if (gi + 2 < ngroups) dma_group(gi + 2, (g + 2) % 3);
-                if (g == 0 && u == 0) {                                 // the raw residual tile: 48 rows of this lane's position
-                    // buffer loads: one lane offset + the row's offset in an SGPR (48 plain loads keep 96 address registers live)
-                    const int mc = m < a.L ? m : a.L - 1;
-                    const unsigned voff = (unsigned)(4 * h * a.cs + mc) * 4u;
-#pragma unroll
-                    for (int i = 0; i < TN; i++) {
-                        __amdgpu_buffer_rsrc_t rs = row_tile_rsrc(xu, i);
-#pragma unroll
-                        for (int r = 0; r < 16; r++)
-                            y[i][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, (unsigned)((r & 3) + 8 * (r >> 2)) * row_bytes, 0));
-                    }
-                }
-                if (g == 0 && u == 2 && has_next) x_fetch(t0 + BM);
-                const unsigned char *rb = Ring + (g % 3) * GRP;
-#pragma unroll
-                for (int s = 0; s < GSL; s++) {
-                    const int st = g * GSL + s;
-                    if (st < 21) {                                      // conv7 slot: channel block cb, tap
-                        const int cb = st / 7, tap = st - cb * 7;
-                        const bf16x8 *wsb = reinterpret_cast<const bf16x8 *>(rb + s * SLOT) + l31;
-                        const bf16x8 *xt = reinterpret_cast<const bf16x8 *>(xsb + tap * d);
-#pragma unroll
-                        for (int ks = 0; ks < 2; ks++) {
-                            const int kq = ks * 2 + h;
-                            const bf16x8 bv = xt[(cb * 4 + kq) * XWB];
-                            bf16x8 av[TN];
-#pragma unroll
-                            for (int i = 0; i < TN; i++) av[i] = wsb[kq * C + i * 32];
-#pragma unroll
-                            for (int i = 0; i < TN; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv, acc[i], 0, 0, 0);
-                        }
-                        if (st == 20) {
-                            // H = snake2(acc + b1) -> the 1x1 conv's bf16 B operands (registers 8g..8g+7 of tile i = its eight k)
-#pragma unroll
-                            for (int i = 0; i < TN; i++) {
-#pragma unroll
-                                for (int r = 0; r < 16; r++) {
-                                    const int n = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                                    if (r & 1) {
-                                        f32x2 hv = snake_beta2(mk2(acc[i][r - 1] + P1[n - 1], acc[i][r] + P1[n]), mk2(P1[C + n - 1], P1[C + n]),
-                                                               mk2(P1[2 * C + n - 1], P1[2 * C + n]));
-                                        acc[i][r - 1] = hv.x;
-                                        acc[i][r] = hv.y;
-                                    }
-                                    if ((r & 3) == 3) {
-                                        asm volatile("" : "+v"(acc[i][r - 3]), "+v"(acc[i][r - 2]), "+v"(acc[i][r - 1]), "+v"(acc[i][r]));
-                                        __builtin_amdgcn_sched_barrier(0);
-                                    }
-                                }
-#pragma unroll
-                                for (int gg = 0; gg < 2; gg++)
-#pragma unroll
-                                    for (int j = 0; j < 8; j++) hb[i][gg][j] = (__bf16)acc[i][8 * gg + j];
-                            }
-                            // every wave has read this unit's operand tile for the last time
-                            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                            // history: the last 6d positions of this unit's operand, kept by the waves that own them ...
-                            const int hu = 6 * d, hbase = u == 0 ? 0 : (u == 1 ? hoff1 : hoff2);
-                            if (wave * 32 + 32 > BM - hu) {             // (wave-uniform)
-                                const int pj = wave * 32 + l31 - (BM - hu);
-                                if (pj >= 0) {
-#pragma unroll
-                                    for (int k2 = 0; k2 < KG / 2; k2++) {
-                                        const int kg = 2 * k2 + h;
-                                        Hs[hbase + kg * hu + pj] = Ab[kg * XWB + HMAX + wave * 32 + l31];
-                                    }
-                                }
-                            }
-                            // ... and the next unit's history (kept during the previous step) in front of the tile
-                            {
-                                const int un = u == 2 ? 0 : u + 1;
-                                const int dn = un == 0 ? d0 : (un == 1 ? d1 : d2), hn = 6 * dn, hnb = un == 0 ? 0 : (un == 1 ? hoff1 : hoff2);
-                                for (int e = tid; e < KG * hn; e += NTH) {
-                                    const int kg = e / hn, j = e - kg * hn;
-                                    Ab[kg * XWB + HMAX - hn + j] = Hs[hnb + e];
-                                }
-                            }
-                        }
-                    } else {                                            // 1x1 conv, output tile o: y += W2 h + b2; then what follows the unit
-                        const int o = st - 21;
-                        f32x16 acc2;
-#pragma unroll
-                        for (int r = 0; r < 16; r++) acc2[r] = 0.0f;
-                        const bf16x8 *ws2 = reinterpret_cast<const bf16x8 *>(rb + s * SLOT) + h * 32 + l31;
-#pragma unroll
-                        for (int i = 0; i < TN; i++)
-#pragma unroll
-                            for (int gg = 0; gg < 2; gg++) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ws2[(i * 2 + gg) * 64], hb[i][gg], acc2, 0, 0, 0);
-#pragma unroll
-                        for (int half = 0; half < 2; half++) {
-                            int n[8];
-                            float v[8], w[8];
-#pragma unroll
-                            for (int q = 0; q < 8; q++) {
-                                const int r = half * 8 + q;
-                                n[q] = o * 32 + 4 * h + (r & 3) + 8 * (r >> 2);
-                            }
-#pragma unroll
-                            for (int q = 0; q < 8; q++) {
-                                v[q] = y[o][half * 8 + q] + (acc2[half * 8 + q] + P1[3 * C + n[q]]);
-                                y[o][half * 8 + q] = v[q];
-                                w[q] = v[q];
-                            }
-                            const bool act = u < 2 || a.psn_a[2] != nullptr;
-                            if (act) {
-#pragma unroll
-                                for (int q = 0; q < 8; q += 2) {
-                                    f32x2 sv = snake_beta2(mk2(v[q], v[q + 1]), mk2(P1[4 * C + n[q]], P1[4 * C + n[q + 1]]),
-                                                           mk2(P1[5 * C + n[q]], P1[5 * C + n[q + 1]]));
-                                    w[q] = sv.x; w[q + 1] = sv.y;
-                                }
-                            }
-                            if (u < 2) {                                // the next unit's operand, in place
-#pragma unroll
-                                for (int g2 = 0; g2 < 2; g2++) {
-                                    const int kg = n[4 * g2] >> 3;
-                                    uint2 *dst = reinterpret_cast<uint2 *>(Ab + kg * XWB + HMAX + wave * 32 + l31) + h;
-                                    *dst = pack4_bf16(w[4 * g2], w[4 * g2 + 1], w[4 * g2 + 2], w[4 * g2 + 3]);
-                                }
-                            } else if (stored && m < a.L) {             // the block's output
-                                const unsigned voff = (unsigned)(4 * h * a.cs + m) * 4u;
-                                if (yu) {
-                                    __amdgpu_buffer_rsrc_t rs = row_tile_rsrc(yu, o);
-#pragma unroll
-                                    for (int q = 0; q < 8; q++) {
-                                        const int r = half * 8 + q;
-                                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ybu ? v[q] : w[q]), rs, voff,
-                                                                              (unsigned)((r & 3) + 8 * (r >> 2)) * row_bytes, 0);
-                                    }
-                                }
-                                if (ybu) {
-#pragma unroll
-                                    for (int g2 = 0; g2 < 2; g2++)
-                                        *reinterpret_cast<uint2 *>(ybu + ((((long)(n[4 * g2] >> 3) * a.cs + m) << 3) + (n[4 * g2] & 4))) =
-                                            pack4_bf16(w[4 * g2], w[4 * g2 + 1], w[4 * g2 + 2], w[4 * g2 + 3]);
-                                }
-                            }
-                        }
-                        if (st == 23 && u == 2 && has_next) {           // the next step's operand tile, over everybody's positions:
-                            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // ... once the owners have kept their history
-                            x_commit(t0 + BM);
-                        }
-                    }
-                }
-            }
+            bf16x8 w2q[2 * TN];                                         // the 1x1 conv's A operands of one output tile
+            // LDS byte addresses of this lane's operands: tap t of its position is + 16 t d; k-group rows and slots are immediates
+            const unsigned xs_addr = ab_lds + (unsigned)((h * XWB + HMAX + wave * 32 + l31 - 6 * d) * 16);
+            const unsigned d16 = (unsigned)d * 16u;
+            static_assert(UGR == 6, "six groups per unit");
+#define B3_G 0
+#include "kernels_blk3_group.inc"
+#undef B3_G
+#define B3_G 1
+#include "kernels_blk3_group.inc"
+#undef B3_G
+#define B3_G 2
+#include "kernels_blk3_group.inc"
+#undef B3_G
+#define B3_G 3
+#include "kernels_blk3_group.inc"
+#undef B3_G
+#define B3_G 4
+#include "kernels_blk3_group.inc"
+#undef B3_G
+#define B3_G 5
+#include "kernels_blk3_group.inc"
+#undef B3_G
         }
     }
 }
