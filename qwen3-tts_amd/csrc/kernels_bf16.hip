@@ -46,12 +46,16 @@ __device__ __forceinline__ bf16x8 pack8(const f32x8 &v) {
 // mid = bf16(v - hi) (16 mantissa bits together), and a product is three MFMAs: hi*hi + hi*mid + mid*hi (the dropped
 // mid*mid term is 2^-16 of the product).  fp32-grade results at a third of the bf16 MFMA rate -- still several
 // times the fp32 MFMA rate.  Weights are split once at load (ConvGemmArgs::wbm / wb2m), activations at commit.
-template <int TN, bool FUSE, bool XB, bool X3, int OI = 0>      // OI: 0, or ConvGemmArgs::pm of a transposed conv with its own epilogue (2, 3)
+// NW: waves per workgroup (32 positions each).  8 by default; 4 (HIPVOC_BF16_W4=1) for the packed fused residual units: two
+// INDEPENDENT workgroups per CU instead of one, the move that paid off for the fp32 kernels -- here it does not
+// (see bf16_w4 below).  Same MFMA chain per output element either way.
+template <int TN, bool FUSE, bool XB, bool X3, int OI = 0, int NW = 8>      // OI: 0, or ConvGemmArgs::pm of a transposed conv with its own epilogue (2, 3)
 __device__ __forceinline__ void conv_gemm_bf16_body(const ConvGemmArgs &a, int HL, int XW, int tiles_per_unit, int n_tiles) {
+    constexpr int BMB = 32 * NW, NTHB = 64 * NW;      // (shadow the 8-wave constants of this file)
     constexpr int BN = TN * 32;
     constexpr int WF = 4 * BN;                        // 16-byte elements per W tile [4 k-groups][BN rows]
-    constexpr int WPT = (WF + NTHB - 1) / NTHB;       // per thread: 1 (TN <= 4) or 2 (TN = 6)
-    static_assert(WPT <= 2, "W staging registers");
+    constexpr int WPT = (WF + NTHB - 1) / NTHB;       // per thread: 1 (TN <= 4) or 2 (TN = 6); 3 for TN = 6 in 4 waves
+    static_assert(WPT <= 3, "W staging registers");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
     constexpr int PMF = (FUSE ? 6 : 4) * BN;                     // per-row parameter table (device_common.h), first in LDS
     float *Pm = reinterpret_cast<float *>(smem_all);
@@ -97,15 +101,18 @@ __device__ __forceinline__ void conv_gemm_bf16_body(const ConvGemmArgs &a, int H
     // ---- W staging: the packed tensor is [tap][cb][4 k-groups][NP rows] of 16-byte elements
     const uint4 *wg = reinterpret_cast<const uint4 *>(a.wb);
     const uint4 *wgm = reinterpret_cast<const uint4 *>(a.wbm);
-    uint4 w0 = make_uint4(0, 0, 0, 0), w1 = w0, wm0 = w0, wm1 = w0;
+    uint4 w0 = make_uint4(0, 0, 0, 0), w1 = w0, w2r = w0, wm0 = w0, wm1 = w0;
     const int wq0 = tid / BN, wr0 = tid - wq0 * BN;
     const int wq1 = (tid + NTHB) / BN, wr1 = tid + NTHB - wq1 * BN;
+    const int wq2 = (tid + 2 * NTHB) / BN, wr2 = tid + 2 * NTHB - wq2 * BN;
+    static_assert(!(X3 && WPT > 2), "the split-operand mode runs in 8-wave workgroups");
 #define W_LOAD(stage_)                                                                          \
     {                                                                                           \
         int cb_ = (stage_) / a.ntaps, tap_ = (stage_)-cb_ * a.ntaps;                            \
         const uint4 *wp_ = wg + ((long)(tap_ * ncb + cb_) * 4) * a.NP + n0;                     \
         if (WF >= NTHB || tid < WF) w0 = wp_[(long)wq0 * a.NP + wr0];                           \
-        if constexpr (WPT > 1) if (tid + NTHB < WF) w1 = wp_[(long)wq1 * a.NP + wr1];           \
+        if constexpr (WPT > 1) if (WF >= 2 * NTHB || tid + NTHB < WF) w1 = wp_[(long)wq1 * a.NP + wr1];           \
+        if constexpr (WPT > 2) if (tid + 2 * NTHB < WF) w2r = wp_[(long)wq2 * a.NP + wr2];      \
         if constexpr (X3) {                                                                     \
             const uint4 *wpm_ = wgm + ((long)(tap_ * ncb + cb_) * 4) * a.NP + n0;               \
             if (WF >= NTHB || tid < WF) wm0 = wpm_[(long)wq0 * a.NP + wr0];                     \
@@ -116,7 +123,8 @@ __device__ __forceinline__ void conv_gemm_bf16_body(const ConvGemmArgs &a, int H
     {                                                                                           \
         uint4 *ws_ = reinterpret_cast<uint4 *>(Ws) + (buf_)*WF + tid;                           \
         if (WF >= NTHB || tid < WF) *ws_ = w0;                                                  \
-        if constexpr (WPT > 1) if (tid + NTHB < WF) ws_[NTHB] = w1;                             \
+        if constexpr (WPT > 1) if (WF >= 2 * NTHB || tid + NTHB < WF) ws_[NTHB] = w1;           \
+        if constexpr (WPT > 2) if (tid + 2 * NTHB < WF) ws_[2 * NTHB] = w2r;                    \
         if constexpr (X3) {                                                                     \
             uint4 *wsm_ = reinterpret_cast<uint4 *>(Wm) + (buf_)*WF + tid;                      \
             if (WF >= NTHB || tid < WF) *wsm_ = wm0;                                            \
@@ -298,6 +306,8 @@ __device__ __forceinline__ void conv_gemm_bf16_body(const ConvGemmArgs &a, int H
         const uint4 *w2g = reinterpret_cast<const uint4 *>(launder_after(a.wb2, acc[0][15]));
         if (tid < W2N) w0 = w2g[tid];
         if constexpr (W2N > NTHB) if (tid + NTHB < W2N) w1 = w2g[tid + NTHB];
+        if constexpr (W2N > 2 * NTHB) if (tid + 2 * NTHB < W2N) w2r = w2g[tid + 2 * NTHB];
+        static_assert(W2N <= 3 * NTHB, "W2 staging registers");
         if constexpr (X3) {
             const uint4 *w2gm = reinterpret_cast<const uint4 *>(launder_after(a.wb2m, acc[0][15]));
             if (tid < W2N) wm0 = w2gm[tid];
@@ -337,6 +347,7 @@ __device__ __forceinline__ void conv_gemm_bf16_body(const ConvGemmArgs &a, int H
         __syncthreads();                          // every wave is done with the main loop's tiles
         if (tid < W2N) w2s[tid] = w0;
         if constexpr (W2N > NTHB) if (tid + NTHB < W2N) w2s[tid + NTHB] = w1;
+        if constexpr (W2N > 2 * NTHB) if (tid + 2 * NTHB < W2N) w2s[tid + 2 * NTHB] = w2r;
         if constexpr (X3) {
             if (tid < W2N) w2sm[tid] = wm0;
             if constexpr (W2N > NTHB) if (tid + NTHB < W2N) w2sm[tid + NTHB] = wm1;
@@ -348,6 +359,7 @@ __device__ __forceinline__ void conv_gemm_bf16_body(const ConvGemmArgs &a, int H
                 const uint4 *wq_ = reinterpret_cast<const uint4 *>(launder_after(a.wb2, dep2)) + (o + 1) * W2N;
                 if (tid < W2N) w0 = wq_[tid];
                 if constexpr (W2N > NTHB) if (tid + NTHB < W2N) w1 = wq_[tid + NTHB];
+                if constexpr (W2N > 2 * NTHB) if (tid + 2 * NTHB < W2N) w2r = wq_[tid + 2 * NTHB];
                 if constexpr (X3) {
                     const uint4 *wqm_ = reinterpret_cast<const uint4 *>(launder_after(a.wb2m, dep2)) + (o + 1) * W2N;
                     if (tid < W2N) wm0 = wqm_[tid];
@@ -382,6 +394,7 @@ __device__ __forceinline__ void conv_gemm_bf16_body(const ConvGemmArgs &a, int H
                 uint4 *wd_ = w2s + ((o + 1) & 1) * W2N;
                 if (tid < W2N) wd_[tid] = w0;
                 if constexpr (W2N > NTHB) if (tid + NTHB < W2N) wd_[tid + NTHB] = w1;
+                if constexpr (W2N > 2 * NTHB) if (tid + 2 * NTHB < W2N) wd_[tid + 2 * NTHB] = w2r;
                 if constexpr (X3) {
                     uint4 *wdm_ = w2sm + ((o + 1) & 1) * W2N;
                     if (tid < W2N) wdm_[tid] = wm0;
@@ -416,6 +429,11 @@ __global__ __launch_bounds__(NTHB, (TN > 4) ? 2 : 4) void conv_gemm_bf16_kernel(
                                                                                  int tiles_per_unit, int n_tiles) {
     conv_gemm_bf16_body<TN, FUSE, XB, false>(a, HL, XW, tiles_per_unit, n_tiles);
 }
+// the packed fused residual unit in 4-wave workgroups of 128 positions (two independent workgroups per CU)
+template <int TN>
+__global__ __launch_bounds__(256, 2) void conv_gemm_bf16_w4_kernel(ConvGemmArgs a, int HL, int XW, int tiles_per_unit, int n_tiles) {
+    conv_gemm_bf16_body<TN, true, true, false, 0, 4>(a, HL, XW, tiles_per_unit, n_tiles);
+}
 // the split-operand mode (fp32 exchange between kernels; one 8-wave workgroup per CU)
 template <int TN, bool FUSE>
 __global__ __launch_bounds__(NTHB, 2) void conv_gemm_bf16x3_kernel(ConvGemmArgs a, int HL, int XW, int tiles_per_unit,
@@ -444,9 +462,19 @@ __global__ __launch_bounds__(NTHB, 2) void conv_gemm_bf16x3_pt_kernel(ConvGemmAr
 }
 
 // ---------------------------------------------------------------------------------------------------
+// HIPVOC_BF16_W4=1: the packed fused residual units in 4-wave workgroups (conv_gemm_bf16_w4_kernel).  Built, bit-identical
+// (tests/test_gpu_bf16.py) and measured SLOWER on MI355X -- block 2's units 6.94 -> 7.32 ms, block 3's 7.08 -> 7.45 ms per pass
+// (profiles/r03_steps_bf16_w4_vs_w8.txt): twice the weight staging per position and a 43 % halo per MFMA outweigh the two
+// independent workgroups per CU -- so the default stays 8 waves.
+static bool bf16_w4(const ConvGemmArgs &a) {
+    const char *e = getenv("HIPVOC_BF16_W4");      // (read per launch: the tests switch it within one process)
+    const bool on = e ? (atoi(e) != 0) : false;
+    return on && a.wb2 && a.xb && !a.wbm && (a.NP == 96 || a.NP == 192);
+}
+
 size_t conv_gemm_bf16_lds_bytes(const ConvGemmArgs &a) {
     int HL, XW;
-    detail::conv_gemm_geometry(a, HL, XW);
+    detail::conv_gemm_geometry(a, HL, XW, bf16_w4(a) ? 128 : 256);
     const int tn = detail::conv_gemm_launch_tn(a);
     const int CinP = (a.Cin + BKB - 1) / BKB * BKB;
     const size_t planes = a.wbm ? 2 : 1;
@@ -480,6 +508,7 @@ const char *conv_gemm_bf16_kernel_name(const ConvGemmArgs &a) {
         }
         return m;
     }
+    if (bf16_w4(a)) return tn == 3 ? "conv_gemm_bf16_w4_kernel<3>" : "conv_gemm_bf16_w4_kernel<6>";
     char *n = names[fuse][xbf][tn & 7];
     if (a.wbm) {
         static char n3[2][8][48];
@@ -553,11 +582,13 @@ hipError_t launch_conv_gemm_bf16(const ConvGemmArgs &a_in, hipStream_t s) {
         a.dbg = dbg;
     }
     int HL, XW;
-    detail::conv_gemm_geometry(a, HL, XW);
+    const bool w4 = bf16_w4(a);
+    const int nth = w4 ? 256 : NTHB, bm = w4 ? 128 : BMB;
+    detail::conv_gemm_geometry(a, HL, XW, bm);
     if (a.M <= 0 || a.units <= 0) return hipSuccess;
     // host-side shape checks: what the kernel's staging loops and vector accesses assume
     if (!a.wb || (a.NP % (32 * a.TN)) || a.NP < a.N || a.TN < 1 || (a.TN > 4 && !(a.pm == 3 && a.TN == 5)) || ((uintptr_t)a.wb & 15) || a.ntaps < 1 ||
-        a.S < 1 || 4 * XW > 3 * NTHB ||
+        a.S < 1 || 4 * XW > 3 * nth ||
         (long)a.x_cs * 4 * (BKB + 1) >= 0x7fffffffL)   // 32-bit byte offsets of the buffer loads (a channel block + a row)
         return hipErrorInvalidValue;
     const int tn = detail::conv_gemm_launch_tn(a);
@@ -572,12 +603,28 @@ hipError_t launch_conv_gemm_bf16(const ConvGemmArgs &a_in, hipStream_t s) {
     if (a.wb2 && (a.S != 1 || a.NP != 32 * tn || (a.N + 31) / 32 != tn || tn == 5 || tn > 6 || !a.res || !a.sn2_a ||
                   !a.sn2_ib || !a.bias || !a.bias2 || ((uintptr_t)a.wb2 & 15)))
         return hipErrorInvalidValue;
-    int tiles_per_unit = (a.M + BMB - 1) / BMB;
+    int tiles_per_unit = (a.M + bm - 1) / bm;
     int n_tiles = a.NP / (32 * tn);
     long grid = (long)tiles_per_unit * a.units * n_tiles;
     if (grid > 0x7fffffffL) return hipErrorInvalidValue;
     size_t lds = conv_gemm_bf16_lds_bytes(a);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
+    if (w4) {
+        static std::atomic<bool> done4[64] = {};
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64 && !done4[dev]) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_gemm_bf16_w4_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_gemm_bf16_w4_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            done4[dev] = true;
+        }
+        if (tn == 3) hipLaunchKernelGGL(conv_gemm_bf16_w4_kernel<3>, dim3((unsigned)grid), dim3(256), lds, s, a, HL, XW, tiles_per_unit, n_tiles);
+        else hipLaunchKernelGGL(conv_gemm_bf16_w4_kernel<6>, dim3((unsigned)grid), dim3(256), lds, s, a, HL, XW, tiles_per_unit, n_tiles);
+        return hipGetLastError();
+    }
     if (a.S > 1 && a.pm == 3) {     // phase-tile rows: tile height = stride
         if (a.wb2 || tn != a.S || (tn != 3 && tn != 5) || (a.N / a.S) % 32 || a.N % a.S || a.NP != a.N || a.res || a.rscale || a.act != ACT_NONE)
             return hipErrorInvalidValue;

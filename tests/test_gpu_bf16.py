@@ -241,3 +241,27 @@ def test_bf16_block3_walk_equals_three_unit_launches_bitwise(pkg, synth, unit, f
             assert a.size == b.size and a.size > 0
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (spans, float(np.abs(a - b).max()))
     del v
+
+
+@pytest.mark.parametrize("cfg_name,unit,frames", [("FULL", 64, 125), ("FULL", 5, 13), ("SMALL", 8, 13)])
+def test_bf16_fused_units_in_4_wave_workgroups_bitwise(pkg, synth, cfg_name, unit, frames, monkeypatch):
+    """bf16 mode: the packed fused residual units (blocks 2 / 3) in 4-wave workgroups of 128 positions
+    (conv_gemm_bf16_w4_kernel) against the 8-wave form (HIPVOC_BF16_W4=0): the same MFMA chain per output element, so the
+    same bits.  (HIPVOC_BLK3=0 keeps block 3 on the per-unit kernel so that both tile heights are covered.)"""
+    cfg = getattr(synth, cfg_name)
+    path = os.path.join(tempfile.gettempdir(), f"hipvoc_test_{cfg_name}_0.safetensors")
+    if not os.path.exists(path):
+        synth.save_safetensors(path, weights_for(synth, cfg_name, 0), cfg.metadata())
+    codes = synth.make_codes(frames, 41, cfg)
+    monkeypatch.setenv("HIPVOC_BLK3", "0")
+    outs = []
+    for w4 in ("0", "1"):
+        monkeypatch.setenv("HIPVOC_BF16_W4", w4)                  # read at every launch
+        v = pkg.HipVocoder.load(path, device=0, unit_frames=unit, dtype=BF16)
+        v.set_profile(True)
+        outs.append(v.synthesize(codes))
+        if cfg_name == "FULL":
+            used = sorted(k for k in v.last_profile() if "w4_kernel" in k)
+            assert (len(used) == 2) == (w4 == "1"), (w4, sorted(v.last_profile()))
+        del v
+    assert outs[0].size and np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
