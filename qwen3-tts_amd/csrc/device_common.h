@@ -28,7 +28,26 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // quadrant-select sin/cos pair.
 __device__ __forceinline__ f32x2 mk2(float a, float b) { f32x2 v = {a, b}; return v; }
 __device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+#ifndef HIPVOC_SNAKE_SCALAR
+#define HIPVOC_SNAKE_SCALAR 0     // 1: the same chain on each component with scalar fp32 instructions (component-wise IEEE: same bits)
+#endif
+__device__ __forceinline__ float sin_sq1(float t) {
+    float n = __builtin_rintf(t * 0.31830988618379067154f);
+    float r = __builtin_fmaf(n, -3.140625f, t);
+    r = __builtin_fmaf(n, -9.675025939941406e-4f, r);
+    r = __builtin_fmaf(n, -1.5099580252808664e-7f, r);
+    float z = r * r;
+    float p = __builtin_fmaf(SINSQ_C5, z, SINSQ_C4);
+    p = __builtin_fmaf(p, z, SINSQ_C3);
+    p = __builtin_fmaf(p, z, SINSQ_C2);
+    p = __builtin_fmaf(p, z, SINSQ_C1);
+    p = __builtin_fmaf(p, z, 1.0f);
+    return z * p;
+}
 __device__ __forceinline__ f32x2 sin_sq2(f32x2 t) {
+#if HIPVOC_SNAKE_SCALAR
+    return mk2(sin_sq1(t.x), sin_sq1(t.y));
+#else
     f32x2 n = __builtin_elementwise_rint(t * 0.31830988618379067154f);
     f32x2 r = fma2(n, (f32x2)(-3.140625f), t);
     r = fma2(n, (f32x2)(-9.675025939941406e-4f), r);
@@ -40,6 +59,7 @@ __device__ __forceinline__ f32x2 sin_sq2(f32x2 t) {
     p = fma2(p, z, (f32x2)(SINSQ_C1));
     p = fma2(p, z, (f32x2)(1.0f));
     return z * p;
+#endif
 }
 __device__ __forceinline__ float sin_sq(float t) {
     f32x2 v = sin_sq2((f32x2)(t));
@@ -66,7 +86,13 @@ __device__ __forceinline__ T *launder_after(T *p, float dep) {
 }
 
 // SnakeBeta: x + 1/(e^beta + 1e-9) * sin(x e^alpha)^2.  The pair form is what the kernels use; both round identically.
-__device__ __forceinline__ f32x2 snake_beta2(f32x2 x, f32x2 ea, f32x2 ib) { return fma2(ib, sin_sq2(x * ea), x); }
+__device__ __forceinline__ f32x2 snake_beta2(f32x2 x, f32x2 ea, f32x2 ib) {
+#if HIPVOC_SNAKE_SCALAR
+    return mk2(__builtin_fmaf(ib.x, sin_sq1(x.x * ea.x), x.x), __builtin_fmaf(ib.y, sin_sq1(x.y * ea.y), x.y));
+#else
+    return fma2(ib, sin_sq2(x * ea), x);
+#endif
+}
 __device__ __forceinline__ float snake_beta(float x, float ea, float ib) {
     f32x2 v = snake_beta2((f32x2)(x), (f32x2)(ea), (f32x2)(ib));
     return v.x;

@@ -1,0 +1,293 @@
+// gfx950 (CDNA4 / MI355X), bf16 conv-GEMM mode: the causal k = 7 convs of the decoder blocks whose operand is a packed bf16
+// tensor (ConvGemmArgs::xb), with BOTH operands staged by LDS-DMA through a ring (conv7_bf16_ring_kernel).
+//
+// conv_gemm_bf16_kernel stages every (channel block, tap) weight tile through registers ONE stage ahead, with a barrier per
+// stage of 8 MFMAs per wave: the tile's L2 round trip (~1 us) does not fit into a stage (~0.4 us with four waves per SIMD), so
+// every stage waits, and a wave reads five 16-byte LDS operands for four MFMAs (profiles/r03_pmc_sq_bf16_before.txt: matrix
+// pipe busy 55-60 % of the cycles on these layers).  Here:
+//   * the packed activation element [c/8][unit][t][8 bf16] IS the LDS tile element, and the weights lie in HBM in LDS tile
+//     order, so both arrive by global_load_lds_dwordx4: no staging registers, no commit pass, and a weight tile is in flight
+//     THREE stages ahead (ring of four 8 KB slots), the activation tile of the next channel block seven stages ahead
+//     (double buffer);
+//   * a wave owns 128 rows x 64 positions (4 x 2 accumulator tiles): six LDS operand reads feed eight MFMAs;
+//   * 4-wave workgroups of 256 positions, 75 KB of LDS: two INDEPENDENT workgroups per CU, so one's barrier and epilogue
+//     overlap the other's MFMAs (the move that paid off for the fp32 kernels);
+//   * s_waitcnt vmcnt(N) at a stage's barrier names how many YOUNGER operations may stay in flight (they complete in issue
+//     order): the weight tiles of the next two stages, plus the next activation tile during the three stages after its issue.
+// Per output element the chain of MFMAs is conv_gemm_bf16_kernel's (channel blocks of 32 ascending, taps ascending, k-groups
+// ascending with lane half h supplying group 2 ks + h) and the epilogue is the same function: results are BIT-IDENTICAL
+// (tests/test_gpu_bf16.py), so the choice may depend on the launch size without breaking batch == single.
+#include "device_common.h"
+#include "kernels.h"
+
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+
+namespace hipvoc {
+
+typedef __bf16 rg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void *rg_lptr_t;
+typedef const __attribute__((address_space(3))) rg_bf16x8 *rg_lds16_t;
+
+#ifndef RG_ABL
+#define RG_ABL 0          // timing-only experiments (results are wrong with any bit set): 1 = no weight DMA after the prologue,
+#endif                    // 2 = no activation DMA after the prologue, 4 = no barriers, 16 = no LDS operand reads
+
+namespace ring {
+constexpr int NW = 4, NTH = 64 * NW;        // waves per workgroup, threads
+constexpr int PT = 2;                       // 32-position tiles per wave
+constexpr int BM = 32 * PT * NW;            // positions per workgroup
+constexpr int XW = 320;                     // positions per k-group row of the activation tile: BM + the left halo (<= 64), whole pieces
+constexpr int XBUF = 4 * XW * 16;           // bytes per activation tile [4 k-groups][XW][8 bf16]
+constexpr int XP = 4 * XW / 64 / NW;        // 1 KB pieces per wave and activation tile
+constexpr int RW = 4;                       // weight slots in the ring
+constexpr int NTAPS = 7;
+static_assert(4 * XW % (64 * NW) == 0, "every wave issues the same number of activation pieces");
+}  // namespace ring
+
+__device__ __forceinline__ rg_bf16x8 rg_lds16(unsigned addr) {
+#if RG_ABL & 16
+    rg_bf16x8 v;
+    for (int j = 0; j < 8; j++) v[j] = (__bf16)(float)(addr & 7);
+    return v;
+#else
+    return *(rg_lds16_t)(size_t)addr;
+#endif
+}
+
+// 16 bytes per lane from global memory straight into LDS (see b3_dma16 / wn_dma16: inline asm, because the builtin is booked as
+// a flat access and turns every later LDS wait into lgkmcnt(0)).  sbase and lds_addr are wave-uniform.
+__device__ __forceinline__ void rg_dma16(unsigned long long sbase, unsigned voff_bytes, unsigned lds_addr) {
+    const unsigned b_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(sbase >> 32)), b_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sbase);
+    const unsigned long long bs = ((unsigned long long)b_hi << 32) | (unsigned long long)b_lo;
+    const unsigned l = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(l), "v"(voff_bytes), "s"(bs) : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void rg_wait_bar() {
+#if RG_ABL & 4
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(N) : "memory");
+#else
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+#endif
+}
+
+template <int TN>
+__global__ __launch_bounds__(ring::NTH, 2) void conv7_bf16_ring_kernel(ConvGemmArgs a, int tiles_per_unit, int n_tiles) {
+    using namespace ring;
+    constexpr int BN = 32 * TN;
+    constexpr int SLOTB = 4 * BN * 16;              // bytes per weight slot [4 k-groups][BN rows][8 bf16]
+    constexpr int WP = SLOTB / 1024 / NW;           // 1 KB pieces per wave and slot
+    constexpr int PPG = BN / 64;                    // pieces per k-group row
+    static_assert(BN % 64 == 0 && SLOTB % (1024 * NW) == 0, "whole pieces per wave");
+    constexpr int PMB = 4 * BN * 4;                 // per-row parameter table (device_common.h), first in LDS
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *Pm = reinterpret_cast<float *>(smem);
+    uint4 *Xs = reinterpret_cast<uint4 *>(smem + PMB);
+    const unsigned x_lds = (unsigned)(size_t)(rg_lptr_t)(smem + PMB);
+    const unsigned w_lds = x_lds + 2 * XBUF;
+
+    // XCD-aware bijective remap (as conv_gemm_bf16_kernel): the row tiles that share an activation tile run on one L2
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+    const int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    const int nt = id % n_tiles;
+    const int pt_ = id / n_tiles;
+    const int unit = pt_ / tiles_per_unit;
+    const int m0 = (pt_ - unit * tiles_per_unit) * BM;
+    const int n0 = nt * BN;
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int d = a.shift_step, HL = -a.shift0;     // (host: HL == 6 d, BM + HL <= XW)
+    const int ncb = a.Cin / 32;                     // (host: Cin % 32 == 0)
+
+    fill_param_table<BN, false>(a, Pm, n0, tid, NTH);
+    // The causal left padding: the first tile of a unit keeps zeros at positions < 0 of both buffers -- the DMA's lanes for
+    // those positions are masked off, so nothing overwrites them.  (Visible to every wave after the first stage's barrier.)
+    if (m0 == 0) {
+        for (int e = tid; e < 2 * 4 * HL; e += NTH) {
+            const int row = e / HL, t = e - row * HL;
+            Xs[row * XW + t] = make_uint4(0, 0, 0, 0);
+        }
+    }
+
+    // ---- activation pieces of this wave: piece wave + NW j covers the tile's elements 64 (wave + NW j) + lane
+    unsigned xvoff[XP];
+    unsigned xmask = 0;
+#pragma unroll
+    for (int j = 0; j < XP; j++) {
+        const int e = (wave + NW * j) * 64 + lane;
+        const int kg = e / XW, t = e - kg * XW;
+        int pos = m0 - HL + t;
+        if (pos >= 0) xmask |= 1u << j;
+        pos = pos < 0 ? 0 : (pos >= a.Lin ? a.Lin - 1 : pos);
+        xvoff[j] = (unsigned)(((long)kg * a.x_cs + pos) * 16);
+    }
+    const unsigned long long xbase = reinterpret_cast<unsigned long long>(a.xb) + ((unsigned long long)((long)unit * a.x_us) << 4);
+    const unsigned long long xcb_bytes = (unsigned long long)a.x_cs * 64ull;          // 4 k-groups
+    auto dma_x = [&](int cb, int buf) {
+        if ((RG_ABL & 2) && cb > 0) return;
+        const unsigned long long base = xbase + (unsigned long long)cb * xcb_bytes;
+#pragma unroll
+        for (int j = 0; j < XP; j++)
+            if ((xmask >> j) & 1) rg_dma16(base, xvoff[j], x_lds + (unsigned)(buf * XBUF + (wave + NW * j) * 1024));
+    };
+    // ---- weight pieces: slot (cb, tap) is [4 k-groups][BN rows] of the packed tensor [tap][cb][4][NP]; piece p = k-group p / PPG,
+    // rows 64 (p % PPG) ..
+    const unsigned long long wbase = reinterpret_cast<unsigned long long>(a.wb) + ((unsigned long long)n0 << 4);
+    const unsigned long long wkg_bytes = (unsigned long long)a.NP * 16ull;
+    const unsigned wlane = (unsigned)lane * 16u;
+    auto dma_w = [&](int cb, int tap, int slot) {
+        if ((RG_ABL & 1) && (cb > 0 || tap > 2)) return;
+        const unsigned long long base = wbase + (unsigned long long)((tap * ncb + cb) * 4) * wkg_bytes;
+#pragma unroll
+        for (int q = 0; q < WP; q++) {
+            const int p = wave * WP + q, kg = p / PPG, part = p - kg * PPG;
+            rg_dma16(base + (unsigned long long)kg * wkg_bytes + (unsigned long long)(part * 1024), wlane, w_lds + (unsigned)(slot * SLOTB + p * 1024));
+        }
+    };
+
+    f32x16 acc[TN][PT];
+#pragma unroll
+    for (int i = 0; i < TN; i++)
+#pragma unroll
+        for (int p = 0; p < PT; p++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][p][r] = 0.0f;
+
+    dma_x(0, 0);
+    dma_w(0, 0, 0);
+    dma_w(0, 1, 1);
+    dma_w(0, 2, 2);
+
+    // this lane's operand addresses: B = element (k-group 2 ks + h, position 64 wave + 32 p + l31 + tap d) of the activation tile
+    // (tile position 0 = m0 - HL, tap 0 reads position m - 6 d = tile position m - m0), A = (k-group 2 ks + h, row 32 i + l31)
+    const unsigned xaddr0 = x_lds + (unsigned)((h * XW + wave * 64 + l31) * 16);
+    const unsigned waddr0 = w_lds + (unsigned)((h * BN + l31) * 16);
+    const unsigned d16 = (unsigned)d * 16u;
+
+    rg_bf16x8 bq[2][PT];
+    for (int cb = 0; cb < ncb; cb++) {
+        const bool lastcb = cb + 1 == ncb;
+#pragma unroll
+        for (int tap = 0; tap < NTAPS; tap++) {
+            const int st = cb * NTAPS + tap, slot = st & (RW - 1);
+            // this wave's pieces of slot st (and, at tap 0, of this block's activation tile: issued earlier still) have landed;
+            // younger: the slots of the next two stages, and during taps 1-3 the next block's activation tile (issued at tap 0)
+            if (lastcb && tap == NTAPS - 1) rg_wait_bar<0>();
+            else if (lastcb && tap == NTAPS - 2) rg_wait_bar<WP>();
+            else if (!lastcb && tap >= 1 && tap <= 3) rg_wait_bar<2 * WP + XP>();
+            else rg_wait_bar<2 * WP>();
+            // every wave is past stage st - 1: its slot, and at tap 0 the other activation buffer, are free
+            {
+                const int tap3 = (tap + 3) % NTAPS, cb3 = cb + ((tap + 3) >= NTAPS ? 1 : 0);
+                if (cb3 < ncb) dma_w(cb3, tap3, (st + 3) & (RW - 1));
+            }
+            if (tap == 0 && !lastcb) dma_x(cb + 1, (cb + 1) & 1);
+            const unsigned xa = xaddr0 + (unsigned)((cb & 1) * XBUF) + (unsigned)tap * d16;
+            const unsigned wa = waddr0 + (unsigned)(slot * SLOTB);
+            // Operand reads, pinned ahead of the MFMAs (left alone, hipcc emits ds_read -> s_waitcnt -> two v_mfma in series through
+            // sixteen operand registers).  The A operands of this stage first; then the B operands of the NEXT tap, whose activation
+            // tile is this block's and already complete -- only at tap 0 does a stage read its own B operands behind the barrier.
+            rg_bf16x8 aq[2][TN];
+            if (tap == 0) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+                    for (int p = 0; p < PT; p++) bq[ks][p] = rg_lds16(xa + (unsigned)(ks * 2 * XW * 16 + p * 512));
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+                for (int i = 0; i < TN; i++) aq[ks][i] = rg_lds16(wa + (unsigned)(ks * 2 * BN * 16 + i * 512));
+            rg_bf16x8 bn[2][PT];
+            if (tap + 1 < NTAPS) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+                    for (int p = 0; p < PT; p++) bn[ks][p] = rg_lds16(xa + d16 + (unsigned)(ks * 2 * XW * 16 + p * 512));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+                for (int i = 0; i < TN; i++)
+#pragma unroll
+                    for (int p = 0; p < PT; p++) acc[i][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[ks][i], bq[ks][p], acc[i][p], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (tap + 1 < NTAPS) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+                    for (int p = 0; p < PT; p++) bq[ks][p] = bn[ks][p];
+            }
+        }
+    }
+
+    // epilogue (conv_gemm_bf16_kernel's): bias, residual, optional SnakeBeta, fp32 and / or packed stores
+    float *yu = a.y ? a.y + (long)unit * a.y_us : nullptr;
+    const float *ru0 = launder_after(a.res, acc[TN - 1][PT - 1][15]);
+    const float *ru = ru0 ? ru0 + (long)unit * a.y_us : nullptr;
+    float *y2u0 = launder_after(a.y2, acc[TN - 1][PT - 1][15]);
+    float *y2u = y2u0 ? y2u0 + (long)unit * a.y_us : nullptr;
+    unsigned short *ybu0 = launder_after(a.yb, acc[TN - 1][PT - 1][15]);
+    unsigned short *ybu = ybu0 ? ybu0 + (((long)unit * a.y_us) << 3) : nullptr;
+    // (written out: left as loops, hipcc keeps them rolled -- the body is large -- and the accumulators move to scratch)
+    static_assert(PT == 2 && TN <= 6, "the epilogue below is written out for these");
+#define RG_EPI(i_)                                                                                                                    \
+    if constexpr ((i_) < TN) {                                                                                                       \
+        conv_epilogue_tile<BN, false, false>(a, acc[(i_) < TN ? (i_) : 0][0], Pm, n0, (i_)*32 + 4 * h, m0 + wave * 64 + l31, yu, ru, y2u, ybu);      \
+        conv_epilogue_tile<BN, false, false>(a, acc[(i_) < TN ? (i_) : 0][1], Pm, n0, (i_)*32 + 4 * h, m0 + wave * 64 + 32 + l31, yu, ru, y2u, ybu); \
+    }
+    RG_EPI(0) RG_EPI(1) RG_EPI(2) RG_EPI(3) RG_EPI(4) RG_EPI(5)
+#undef RG_EPI
+}
+
+// ---------------------------------------------------------------------------------------------------
+static bool ring_enabled() {
+    const char *e = getenv("HIPVOC_BF16_RING");     // (read per launch: the tests switch it within one process)
+    return e ? atoi(e) != 0 : true;
+}
+
+bool conv7_bf16_ring_selected(const ConvGemmArgs &a) {
+    if (!ring_enabled()) return false;
+    if (!a.wb || !a.xb || a.wb2 || a.wbm || a.sn_a || a.S != 1 || a.ntaps != ring::NTAPS || a.in_elu || a.s2d > 1) return false;
+    if (a.shift_step < 1 || a.shift0 != -6 * a.shift_step || ring::BM - a.shift0 > ring::XW) return false;
+    if ((a.Cin % 32) || a.NP % 128 || a.TN != 4 || a.units < 1 || a.M < 1 || a.Lin < a.M) return false;
+    if ((long)a.x_cs * 16 * 5 >= 0x7fffffffL) return false;          // 32-bit byte offsets of a lane inside a channel block
+    return true;
+}
+
+const char *conv7_bf16_ring_kernel_name(const ConvGemmArgs &) { return "conv7_bf16_ring_kernel<4>"; }
+
+hipError_t launch_conv7_bf16_ring(const ConvGemmArgs &a, hipStream_t s) {
+    using namespace ring;
+    constexpr int TN = 4;
+    if (!conv7_bf16_ring_selected(a)) return hipErrorInvalidValue;
+    // host-side shape checks: what the kernel's indexing and vector accesses assume
+    if (((uintptr_t)a.wb & 15) || ((uintptr_t)a.xb & 15) || (a.yb && ((uintptr_t)a.yb & 15)) || (!a.y && !a.yb) || (a.yb && (a.N & 7)) ||
+        (a.y2 && (!a.psn_a || !a.psn_ib || a.yb)) || a.NP < a.N)
+        return hipErrorInvalidValue;
+    const int tiles_per_unit = (a.M + BM - 1) / BM;
+    const int n_tiles = a.NP / (32 * TN);
+    const long grid = (long)tiles_per_unit * a.units * n_tiles;
+    if (grid > 0x7fffffffL) return hipErrorInvalidValue;
+    constexpr size_t lds = 4 * 32 * TN * 4 + 2 * XBUF + RW * 4 * 32 * TN * 16;
+    static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
+    static std::atomic<bool> done[64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64 && !done[dev]) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv7_bf16_ring_kernel<TN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        done[dev] = true;
+    }
+    hipLaunchKernelGGL(conv7_bf16_ring_kernel<TN>, dim3((unsigned)grid), dim3(NTH), lds, s, a, tiles_per_unit, n_tiles);
+    return hipGetLastError();
+}
+
+}  // namespace hipvoc
