@@ -247,46 +247,246 @@ __global__ __launch_bounds__(ring::NTH, 2) void conv7_bf16_ring_kernel(ConvGemmA
 }
 
 // ---------------------------------------------------------------------------------------------------
-static bool ring_enabled() {
-    const char *e = getenv("HIPVOC_BF16_RING");     // (read per launch: the tests switch it within one process)
-    return e ? atoi(e) != 0 : true;
+// The same conv in ONE 8-wave workgroup of 512 positions per CU, with a ring of EIGHT weight slots (conv7_bf16_ring8_kernel).
+// Timing ablations of the 4-wave form on block 1 (4.02 ms per pass for its three layers): without the weight DMA 3.24, without
+// any DMA 3.05, and without barriers 2.96 -- a weight tile three stages ahead is issued ~1.5 us before its use, about the
+// DMA's issue-to-landing time under load, and every position tile of 256 fetches its own copy of the weights.  Here a slot
+// feeds 512 positions (half the L2 -> LDS weight traffic), is issued SEVEN stages ahead, and the barrier at the top of stage s
+// certifies the slot of stage s + 1 (each wave waits for its own piece of that slot before the barrier): the operands of
+// k-step (s + 1, 0) are read from LDS during the MFMAs of k-step (s, 1), i.e. across the barrier, so no MFMA waits for an LDS
+// read issued behind the barrier it follows.  Two operand register sets alternate per k-step.
+namespace ring8 {
+constexpr int BM = 512;                     // positions per workgroup: NW waves x PT 32-position tiles
+constexpr int XW = 640;                     // BM + the left halo (<= 64) in whole pieces per wave
+constexpr int XBUF = 4 * XW * 16;
+constexpr int RW = 8;
+constexpr int NTAPS = 7;
+static_assert(RW - 1 == NTAPS, "the slot issued at (cb, tap) is (cb + 1, tap)");
+}  // namespace ring8
+
+// NW x PT = 16: eight waves of 64 positions (two per SIMD; the instance that is built), or four waves of 128 positions -- one
+// wave per SIMD with 4 x 4 accumulator tiles in 256 AGPRs, eight LDS operand reads per sixteen MFMAs, the shape library GEMMs
+// use.  That instance was built, is bit-identical too, and measured MUCH slower here (block 1's layers 3.90 -> 5.77 ms per
+// pass, block 0's 2.77 -> 3.53): with one wave per SIMD nothing covers the stage barrier, the DMA's scalar address arithmetic
+// or -- at K = 2 688 -- the epilogue of sixteen tiles, which is a third of the main loop's length.
+template <int TN, int NW, int PT>
+__global__ __launch_bounds__(64 * NW, (NW == 4 ? 1 : 2)) void conv7_bf16_ring8_kernel(ConvGemmArgs a, int tiles_per_unit, int n_tiles) {
+    using namespace ring8;
+    constexpr int NTH = 64 * NW;
+    constexpr int XP = 4 * XW / 64 / NW;            // activation pieces per wave: 5, or 10
+    static_assert(32 * PT * NW == BM && 4 * XW % (64 * NW) == 0, "geometry");
+    constexpr int BN = 32 * TN;
+    constexpr int SLOTB = 4 * BN * 16;
+    constexpr int WP = SLOTB / 1024 / NW;           // 1 for 128 rows
+    constexpr int PPG = BN / 64;
+    static_assert(BN % 64 == 0 && SLOTB % (1024 * NW) == 0 && WP >= 1, "whole pieces per wave");
+    constexpr int PMB = 4 * BN * 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *Pm = reinterpret_cast<float *>(smem);
+    uint4 *Xs = reinterpret_cast<uint4 *>(smem + PMB);
+    const unsigned x_lds = (unsigned)(size_t)(rg_lptr_t)(smem + PMB);
+    const unsigned w_lds = x_lds + 2 * XBUF;
+
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+    const int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    const int nt = id % n_tiles;
+    const int pt_ = id / n_tiles;
+    const int unit = pt_ / tiles_per_unit;
+    const int m0 = (pt_ - unit * tiles_per_unit) * BM;
+    const int n0 = nt * BN;
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int d = a.shift_step, HL = -a.shift0;
+    const int ncb = a.Cin / 32;
+
+    fill_param_table<BN, false>(a, Pm, n0, tid, NTH);
+    if (m0 == 0) {
+        for (int e = tid; e < 2 * 4 * HL; e += NTH) {
+            const int row = e / HL, t = e - row * HL;
+            Xs[row * XW + t] = make_uint4(0, 0, 0, 0);
+        }
+    }
+    unsigned xvoff[XP];
+    unsigned xmask = 0;
+#pragma unroll
+    for (int j = 0; j < XP; j++) {
+        const int e = (wave + NW * j) * 64 + lane;
+        const int kg = e / XW, t = e - kg * XW;
+        int pos = m0 - HL + t;
+        if (pos >= 0) xmask |= 1u << j;
+        pos = pos < 0 ? 0 : (pos >= a.Lin ? a.Lin - 1 : pos);
+        xvoff[j] = (unsigned)(((long)kg * a.x_cs + pos) * 16);
+    }
+    const unsigned long long xbase = reinterpret_cast<unsigned long long>(a.xb) + ((unsigned long long)((long)unit * a.x_us) << 4);
+    const unsigned long long xcb_bytes = (unsigned long long)a.x_cs * 64ull;
+    auto dma_x = [&](int cb, int buf) {
+        if ((RG_ABL & 2) && cb > 0) return;
+        const unsigned long long base = xbase + (unsigned long long)cb * xcb_bytes;
+#pragma unroll
+        for (int j = 0; j < XP; j++)
+            if ((xmask >> j) & 1) rg_dma16(base, xvoff[j], x_lds + (unsigned)(buf * XBUF + (wave + NW * j) * 1024));
+    };
+    const unsigned long long wbase = reinterpret_cast<unsigned long long>(a.wb) + ((unsigned long long)n0 << 4);
+    const unsigned long long wkg_bytes = (unsigned long long)a.NP * 16ull;
+    const unsigned wlane = (unsigned)lane * 16u;
+    auto dma_w = [&](int cb, int tap, int slot) {
+        if ((RG_ABL & 1) && cb > 0) return;
+        const unsigned long long base = wbase + (unsigned long long)((tap * ncb + cb) * 4) * wkg_bytes;
+#pragma unroll
+        for (int q = 0; q < WP; q++) {
+            const int p = wave * WP + q, kg = p / PPG, part = p - kg * PPG;
+            rg_dma16(base + (unsigned long long)kg * wkg_bytes + (unsigned long long)(part * 1024), wlane, w_lds + (unsigned)(slot * SLOTB + p * 1024));
+        }
+    };
+
+    f32x16 acc[TN][PT];
+#pragma unroll
+    for (int i = 0; i < TN; i++)
+#pragma unroll
+        for (int p = 0; p < PT; p++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][p][r] = 0.0f;
+
+    // prologue: the first activation tile, then the slots of stages 0 .. 6 (slot j of the ring = stage j mod 8)
+    dma_x(0, 0);
+#pragma unroll
+    for (int t = 0; t < NTAPS; t++) dma_w(0, t, t);
+
+    const unsigned xaddr0 = x_lds + (unsigned)((h * XW + wave * (32 * PT) + l31) * 16);
+    const unsigned waddr0 = w_lds + (unsigned)((h * BN + l31) * 16);
+    const unsigned d16 = (unsigned)d * 16u;
+
+    // two operand sets, alternating per k-step: set ks holds the operands of k-step (stage, ks)
+    rg_bf16x8 aq[2][TN], bq[2][PT];
+#define RG8_READ(set_, xa_, wa_, ks_)                                                                               \
+    {                                                                                                               \
+        _Pragma("unroll") for (int p = 0; p < PT; p++) bq[set_][p] = rg_lds16((xa_) + (unsigned)((ks_)*2 * XW * 16 + p * 512)); \
+        _Pragma("unroll") for (int i = 0; i < TN; i++) aq[set_][i] = rg_lds16((wa_) + (unsigned)((ks_)*2 * BN * 16 + i * 512)); \
+    }
+#define RG8_MFMA(set_)                                                                                              \
+    {                                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < TN; i++)                                                              \
+            _Pragma("unroll") for (int p = 0; p < PT; p++)                                                          \
+                acc[i][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[set_][i], bq[set_][p], acc[i][p], 0, 0, 0);  \
+    }
+    // slot 0 and the first activation tile: this wave's pieces (younger: the slots of stages 1 .. 6), then everybody's
+    rg_wait_bar<6 * WP>();
+    RG8_READ(0, xaddr0, waddr0, 0)
+
+    for (int cb = 0; cb < ncb; cb++) {
+        const bool lastcb = cb + 1 == ncb;
+#pragma unroll
+        for (int tap = 0; tap < NTAPS; tap++) {
+            const int st = cb * NTAPS + tap;
+            // Certify the slot of stage st + 1 (issued seven stages ago; at tap 6 also the next activation tile, issued before it):
+            // younger operations of this wave are the slots of stages st + 2 .. st + 6, plus, during taps 1 .. 5, the activation
+            // tile of the next block issued at tap 0; in the last block the ring drains (5 - tap slots left behind it).
+            if (lastcb) {
+                if (tap == 0) rg_wait_bar<5 * WP>();
+                else if (tap == 1) rg_wait_bar<4 * WP>();
+                else if (tap == 2) rg_wait_bar<3 * WP>();
+                else if (tap == 3) rg_wait_bar<2 * WP>();
+                else if (tap == 4) rg_wait_bar<1 * WP>();
+                else rg_wait_bar<0>();
+            } else if (tap >= 1 && tap <= 5) rg_wait_bar<5 * WP + XP>();
+            else rg_wait_bar<5 * WP>();
+            // every wave is past stage st - 1 (whose operands it read before this barrier): that slot, and at tap 0 the other
+            // activation buffer, are free.  The activation tile goes FIRST: the wait for slot (cb + 1, 0) at tap 6 then covers it.
+            if (!lastcb) {
+                if (tap == 0) dma_x(cb + 1, (cb + 1) & 1);
+                dma_w(cb + 1, tap, (st + RW - 1) & (RW - 1));
+            }
+            const unsigned xa = xaddr0 + (unsigned)((cb & 1) * XBUF) + (unsigned)tap * d16;
+            const unsigned wa = waddr0 + (unsigned)((st & (RW - 1)) * SLOTB);
+            RG8_READ(1, xa, wa, 1)
+            __builtin_amdgcn_sched_barrier(0);
+            RG8_MFMA(0)
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(lastcb && tap == NTAPS - 1)) {      // k-step (st + 1, 0): the next tap of this tile, or tap 0 of the next block's
+                const unsigned xa1 = tap + 1 < NTAPS ? xa + d16 : xaddr0 + (unsigned)(((cb + 1) & 1) * XBUF);
+                const unsigned wa1 = waddr0 + (unsigned)(((st + 1) & (RW - 1)) * SLOTB);
+                RG8_READ(0, xa1, wa1, 0)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            RG8_MFMA(1)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#undef RG8_READ
+#undef RG8_MFMA
+
+    float *yu = a.y ? a.y + (long)unit * a.y_us : nullptr;
+    const float *ru0 = launder_after(a.res, acc[TN - 1][PT - 1][15]);
+    const float *ru = ru0 ? ru0 + (long)unit * a.y_us : nullptr;
+    float *y2u0 = launder_after(a.y2, acc[TN - 1][PT - 1][15]);
+    float *y2u = y2u0 ? y2u0 + (long)unit * a.y_us : nullptr;
+    unsigned short *ybu0 = launder_after(a.yb, acc[TN - 1][PT - 1][15]);
+    unsigned short *ybu = ybu0 ? ybu0 + (((long)unit * a.y_us) << 3) : nullptr;
+    static_assert(PT <= 4 && TN <= 6, "the epilogue below is written out for these");
+    // (written out: left as loops, hipcc keeps them rolled -- the body is large -- and the accumulators move to scratch)
+#define RG_EPI1(i_, p_)                                                                                                              \
+    if constexpr ((i_) < TN && (p_) < PT)                                                                                            \
+        conv_epilogue_tile<BN, false, false>(a, acc[(i_) < TN ? (i_) : 0][(p_) < PT ? (p_) : 0], Pm, n0, (i_)*32 + 4 * h,            \
+                                             m0 + wave * (32 * PT) + (p_)*32 + l31, yu, ru, y2u, ybu);
+#define RG_EPI(i_) RG_EPI1(i_, 0) RG_EPI1(i_, 1) RG_EPI1(i_, 2) RG_EPI1(i_, 3)
+    RG_EPI(0) RG_EPI(1) RG_EPI(2) RG_EPI(3) RG_EPI(4) RG_EPI(5)
+#undef RG_EPI
+#undef RG_EPI1
+}
+
+// ---------------------------------------------------------------------------------------------------
+static int ring_mode() {
+    // (read per launch: the tests switch it within one process) 0 = off, 1 = the 4-wave form (default), 2 = the 8-wave form, which
+    // measured SLOWER on MI355X (block 1's layers 4.06 -> 4.33 ms per pass, block 0's 2.87 -> 2.93): one workgroup per CU moves in
+    // lock-step again, and neither the deeper ring nor the halved weight traffic makes up for it
+    const char *e = getenv("HIPVOC_BF16_RING");
+    return e ? atoi(e) : 1;
 }
 
 bool conv7_bf16_ring_selected(const ConvGemmArgs &a) {
-    if (!ring_enabled()) return false;
+    if (ring_mode() <= 0) return false;
     if (!a.wb || !a.xb || a.wb2 || a.wbm || a.sn_a || a.S != 1 || a.ntaps != ring::NTAPS || a.in_elu || a.s2d > 1) return false;
-    if (a.shift_step < 1 || a.shift0 != -6 * a.shift_step || ring::BM - a.shift0 > ring::XW) return false;
+    if (a.shift_step < 1 || a.shift0 != -6 * a.shift_step || -a.shift0 > 64) return false;
     if ((a.Cin % 32) || a.NP % 128 || a.TN != 4 || a.units < 1 || a.M < 1 || a.Lin < a.M) return false;
     if ((long)a.x_cs * 16 * 5 >= 0x7fffffffL) return false;          // 32-bit byte offsets of a lane inside a channel block
     return true;
 }
 
-const char *conv7_bf16_ring_kernel_name(const ConvGemmArgs &) { return "conv7_bf16_ring_kernel<4>"; }
+const char *conv7_bf16_ring_kernel_name(const ConvGemmArgs &) {
+    return ring_mode() == 1 ? "conv7_bf16_ring_kernel<4>" : "conv7_bf16_ring8_kernel<4,8,2>";
+}
 
 hipError_t launch_conv7_bf16_ring(const ConvGemmArgs &a, hipStream_t s) {
-    using namespace ring;
     constexpr int TN = 4;
     if (!conv7_bf16_ring_selected(a)) return hipErrorInvalidValue;
-    // host-side shape checks: what the kernel's indexing and vector accesses assume
+    // host-side shape checks: what the kernels' indexing and vector accesses assume
     if (((uintptr_t)a.wb & 15) || ((uintptr_t)a.xb & 15) || (a.yb && ((uintptr_t)a.yb & 15)) || (!a.y && !a.yb) || (a.yb && (a.N & 7)) ||
         (a.y2 && (!a.psn_a || !a.psn_ib || a.yb)) || a.NP < a.N)
         return hipErrorInvalidValue;
-    const int tiles_per_unit = (a.M + BM - 1) / BM;
+    const bool w8 = ring_mode() != 1;
+    const int bm = w8 ? ring8::BM : ring::BM;
+    const int tiles_per_unit = (a.M + bm - 1) / bm;
     const int n_tiles = a.NP / (32 * TN);
     const long grid = (long)tiles_per_unit * a.units * n_tiles;
     if (grid > 0x7fffffffL) return hipErrorInvalidValue;
-    constexpr size_t lds = 4 * 32 * TN * 4 + 2 * XBUF + RW * 4 * 32 * TN * 16;
-    static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
+    constexpr size_t lds4 = 4 * 32 * TN * 4 + 2 * ring::XBUF + ring::RW * 4 * 32 * TN * 16;
+    constexpr size_t lds8 = 4 * 32 * TN * 4 + 2 * ring8::XBUF + ring8::RW * 4 * 32 * TN * 16;
+    static_assert(2 * lds4 <= 160 * 1024 && lds8 <= 160 * 1024, "two 4-wave workgroups, or one 8-wave workgroup, per CU");
     static std::atomic<bool> done[64] = {};
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 64 && !done[dev]) {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv7_bf16_ring_kernel<TN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv7_bf16_ring8_kernel<TN, 8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         done[dev] = true;
     }
-    hipLaunchKernelGGL(conv7_bf16_ring_kernel<TN>, dim3((unsigned)grid), dim3(NTH), lds, s, a, tiles_per_unit, n_tiles);
+    if (w8) hipLaunchKernelGGL((conv7_bf16_ring8_kernel<TN, 8, 2>), dim3((unsigned)grid), dim3(512), lds8, s, a, tiles_per_unit, n_tiles);
+    else hipLaunchKernelGGL(conv7_bf16_ring_kernel<TN>, dim3((unsigned)grid), dim3(ring::NTH), lds4, s, a, tiles_per_unit, n_tiles);
     return hipGetLastError();
 }
 

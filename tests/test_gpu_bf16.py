@@ -269,11 +269,13 @@ def test_bf16_fused_units_in_4_wave_workgroups_bitwise(pkg, synth, cfg_name, uni
 
 @pytest.mark.parametrize("unit,frames,n_seq", [(64, 125, 1), (64, 64, 9), (7, 33, 40), (3, 11, 70)])
 def test_bf16_conv7_ring_kernel_bitwise(pkg, synth, unit, frames, n_seq, monkeypatch):
-    """bf16 mode, blocks 0 / 1: conv7_bf16_ring_kernel (kernels_bf16_ring.hip: both operands by LDS-DMA through a ring, 4-wave
-    workgroups, 4 x 2 accumulator tiles per wave) against conv_gemm_bf16_kernel (HIPVOC_BF16_RING=0) -- the same MFMA chain per
-    output element and the same epilogue, so the same bits: a lone utterance (first tiles with causal zero padding, ragged
-    last tiles), a full pass, and passes of many short units (several units per launch, tiles shorter than a workgroup).
-    HIPVOC_CONVS_WGS=0 keeps the small-launch conv7 kernel out of the way so that every size runs the pair under test."""
+    """bf16 mode, blocks 0 / 1: the conv7 kernels that stage both operands by LDS-DMA through a ring (kernels_bf16_ring.hip) --
+    conv7_bf16_ring_kernel (HIPVOC_BF16_RING=1, the default: 4-wave workgroups of 256 positions, four weight slots) and
+    conv7_bf16_ring8_kernel (=2: one 8-wave workgroup of 512 positions per CU, eight slots, operand reads across the stage barrier) --
+    against conv_gemm_bf16_kernel (=0): the same MFMA chain per output element and the same epilogue, so the same bits: a lone
+    utterance (first tiles with causal zero padding, ragged last tiles), a full pass, and passes of many short units (several
+    units per launch, tiles shorter than a workgroup).  HIPVOC_CONVS_WGS=0 keeps the small-launch conv7 kernel out of the way
+    so that every size runs the kernels under test."""
     cfg = synth.FULL
     path = os.path.join(tempfile.gettempdir(), "hipvoc_test_FULL_0.safetensors")
     if not os.path.exists(path):
@@ -281,14 +283,15 @@ def test_bf16_conv7_ring_kernel_bitwise(pkg, synth, unit, frames, n_seq, monkeyp
     seqs = [synth.make_codes(frames, 177 + i, cfg) for i in range(n_seq)]
     monkeypatch.setenv("HIPVOC_CONVS_WGS", "0")
     outs = []
-    for ring in ("0", "1"):
+    for ring, name in (("0", None), ("1", "conv7_bf16_ring_kernel"), ("2", "conv7_bf16_ring8_kernel<4,8,2>")):
         monkeypatch.setenv("HIPVOC_BF16_RING", ring)              # read at every launch
         v = pkg.HipVocoder.load(path, device=0, unit_frames=unit, dtype=BF16)
         v.set_profile(True)
         outs.append(v.synthesize_batch(seqs))
-        used = sorted(k for k in v.last_profile() if "conv7_bf16_ring_kernel" in k)
-        assert (len(used) == 2) == (ring == "1"), (ring, sorted(v.last_profile()))      # b0_conv7 and b1_conv7
+        used = sorted(k for k in v.last_profile() if "conv7_bf16_ring" in k)
+        assert len(used) == (2 if name else 0) and all(name in k for k in used), (ring, sorted(v.last_profile()))      # b0_conv7 and b1_conv7
         del v
-    for a, b in zip(*outs):
-        assert a.size == b.size and a.size > 0
-        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), float(np.abs(a - b).max())
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert a.size == b.size and a.size > 0
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), float(np.abs(a - b).max())
