@@ -324,9 +324,12 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvGemmArgs &a, const 
         float v[8], t[8];
 #pragma unroll
         for (int q = 0; q < 8; q++) v[q] = acc[half * 8 + q];
+#ifndef EPI_ABL
+#define EPI_ABL 0          // timing-only experiments: 1 = no residual loads (zeros), 2 = no fp32 stores beside a packed output
+#endif
         if (ru) {
 #pragma unroll
-            for (int q = 0; q < 8; q++) t[q] = ru[ok[q] ? ro[q] : 0];
+            for (int q = 0; q < 8; q++) t[q] = (EPI_ABL & 1) ? 0.0f : ru[ok[q] ? ro[q] : 0];
         }
         if (a.bias) {
 #pragma unroll
@@ -369,7 +372,7 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvGemmArgs &a, const 
                     w[q] = sv.x; w[q + 1] = sv.y;
                 }
             }
-            if (yu) {
+            if (yu && !(EPI_ABL & 2)) {
 #pragma unroll
                 for (int q = 0; q < 8; q++)
                     if (ok[q]) yu[o[q]] = v[q];

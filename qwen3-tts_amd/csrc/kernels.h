@@ -91,11 +91,11 @@ bool convs_bf16_selected(const ConvGemmArgs &a);      // conv7 on a small launch
 hipError_t launch_convs_bf16(const ConvGemmArgs &a, hipStream_t s);
 const char *convs_bf16_kernel_name(const ConvGemmArgs &a);
 const char *conv_gemm_bf16_kernel_name(const ConvGemmArgs &a);
-// kernels_bf16_ring.hip (bf16 mode): conv7 over a packed operand with both operands staged by LDS-DMA through a ring;
+// kernels_bf16_ring.hip (bf16 mode): conv7 and the transposed convs over a packed operand with both operands staged by LDS-DMA through a ring;
 // bit-identical to conv_gemm_bf16_kernel (launch_conv_gemm_bf16 dispatches; HIPVOC_BF16_RING=0 turns it off)
-bool conv7_bf16_ring_selected(const ConvGemmArgs &a);
-hipError_t launch_conv7_bf16_ring(const ConvGemmArgs &a, hipStream_t s);
-const char *conv7_bf16_ring_kernel_name(const ConvGemmArgs &a);
+bool conv_bf16_ring_selected(const ConvGemmArgs &a);
+hipError_t launch_conv_bf16_ring(const ConvGemmArgs &a, hipStream_t s);
+const char *conv_bf16_ring_kernel_name(const ConvGemmArgs &a);
 bool wino_selected(const ConvGemmArgs &a);            // kernels_wino.hip: F(2,7) Winograd form of the fp32 k = 7 convs
 hipError_t launch_wino_conv7(const ConvGemmArgs &a, hipStream_t s);
 const char *wino_kernel_name(const ConvGemmArgs &a);

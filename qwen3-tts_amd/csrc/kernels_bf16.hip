@@ -487,7 +487,7 @@ size_t conv_gemm_bf16_lds_bytes(const ConvGemmArgs &a) {
 const char *conv_gemm_bf16_kernel_name(const ConvGemmArgs &a) {
     if (gemm1_bf16_selected(a)) return gemm1_bf16_kernel_name(a);
     if (convs_bf16_selected(a)) return convs_bf16_kernel_name(a);
-    if (conv7_bf16_ring_selected(a)) return conv7_bf16_ring_kernel_name(a);
+    if (conv_bf16_ring_selected(a)) return conv_bf16_ring_kernel_name(a);
     static char names[2][2][8][56];
     int tn = detail::conv_gemm_launch_tn(a);
     int fuse = a.wb2 ? 1 : 0, xbf = a.xb ? 1 : 0;
@@ -576,7 +576,7 @@ static hipError_t launch_one_bf16x3(const ConvGemmArgs &a, int HL, int XW, int t
 hipError_t launch_conv_gemm_bf16(const ConvGemmArgs &a_in, hipStream_t s) {
     if (gemm1_bf16_selected(a_in)) return launch_gemm1_bf16(a_in, s);
     if (convs_bf16_selected(a_in)) return launch_convs_bf16(a_in, s);
-    if (conv7_bf16_ring_selected(a_in)) return launch_conv7_bf16_ring(a_in, s);
+    if (conv_bf16_ring_selected(a_in)) return launch_conv_bf16_ring(a_in, s);
     ConvGemmArgs a = a_in;
     {
         static int dbg = -1;

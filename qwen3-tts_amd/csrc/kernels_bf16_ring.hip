@@ -247,6 +247,224 @@ __global__ __launch_bounds__(ring::NTH, 2) void conv7_bf16_ring_kernel(ConvGemmA
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The 4-wave ring kernel for any tap count >= 2 and any tile height (conv_bf16_ring_kernel<TN, NTAPS, EPI, RW>): also the
+// decoder blocks' TRANSPOSED convs (two taps; rows = (channel, phase) in the octet-interleaved or phase-tile order of
+// device_common.h, EPI = 2 / 3 = ConvGemmArgs::pm).  What differs from the kernel above:
+//   * the wait at a stage's barrier is COUNTED at run time: the wave keeps the number of vector-memory operations it has issued
+//     and, per ring slot and activation buffer, the count right after that tile's last piece; "operations younger than what
+//     this stage needs" is a subtraction of wave-uniform scalars, dispatched to the s_waitcnt immediates through a switch.  No
+//     per-schedule table of constants: with two taps the next activation tile is issued only two stages ahead and is YOUNGER
+//     than the weight slot of the stage that first reads it, which the fixed counts above do not cover;
+//   * a weight slot is [4 k-groups][BN rows] for any BN: 1 KB pieces of 64 consecutive elements with per-lane source offsets
+//     (a piece may straddle two k-group rows), dealt to the waves round-robin (waves may differ by one piece per slot);
+//   * RW = 3 slots where 32 TN rows x 4 slots would not leave room for two workgroups per CU (TN = 5).
+template <int N>
+__device__ __forceinline__ void rg_wait_only() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void rg_wait_dyn(int n) {          // n wave-uniform; a smaller immediate than n only waits longer
+#define RG_W(k_) case k_: rg_wait_only<k_>(); break;
+    switch (n) {
+        RG_W(0) RG_W(1) RG_W(2) RG_W(3) RG_W(4) RG_W(5) RG_W(6) RG_W(7) RG_W(8) RG_W(9) RG_W(10) RG_W(11) RG_W(12)
+        RG_W(13) RG_W(14) RG_W(15) RG_W(16) RG_W(17) RG_W(18) RG_W(19) RG_W(20) RG_W(21) RG_W(22) RG_W(23)
+        default: rg_wait_only<24>(); break;
+    }
+#undef RG_W
+}
+
+template <int TN, int NTAPS, int EPI, int RW>
+__global__ __launch_bounds__(ring::NTH, 2) void conv_bf16_ring_kernel(ConvGemmArgs a, int HL, int tiles_per_unit, int n_tiles) {
+    using namespace ring;
+    static_assert(NTAPS >= 2 && RW >= 3 && RW <= 4, "see the header comment");
+    constexpr int BN = 32 * TN;
+    constexpr int SLOTB = 4 * BN * 16;              // bytes per weight slot [4 k-groups][BN rows][8 bf16]
+    constexpr int NPIECES = SLOTB / 1024;           // 2 TN
+    constexpr int WPMAX = (NPIECES + NW - 1) / NW;
+    constexpr int PMB = 4 * BN * 4;
+    constexpr bool BNEXT = NTAPS > 2 && TN <= 4;    // the next tap's B operands are read during this stage's MFMAs (16 registers)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *Pm = reinterpret_cast<float *>(smem);
+    uint4 *Xs = reinterpret_cast<uint4 *>(smem + PMB);
+    const unsigned x_lds = (unsigned)(size_t)(rg_lptr_t)(smem + PMB);
+    const unsigned w_lds = x_lds + 2 * XBUF;
+
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+    const int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    const int nt = id % n_tiles;
+    const int pt_ = id / n_tiles;
+    const int unit = pt_ / tiles_per_unit;
+    const int m0 = (pt_ - unit * tiles_per_unit) * BM;
+    const int n0 = nt * BN;
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int ncb = a.Cin / 32;                     // (host: Cin % 32 == 0)
+    const int nstage = ncb * NTAPS;
+
+    fill_param_table<BN, false>(a, Pm, n0, tid, NTH);
+    // tile position t holds input position m0 - HL + t (HL = the left halo, host); positions < 0 stay zero in both buffers (the
+    // DMA's lanes for them are masked off), positions >= Lin repeat the last one and only reach outputs that are not stored
+    if (m0 - HL < 0) {
+        const int nz = HL - m0;
+        for (int e = tid; e < 2 * 4 * nz; e += NTH) {
+            const int row = e / nz, t = e - row * nz;
+            Xs[row * XW + t] = make_uint4(0, 0, 0, 0);
+        }
+    }
+    unsigned xvoff[XP];
+    unsigned xmask = 0;
+#pragma unroll
+    for (int j = 0; j < XP; j++) {
+        const int e = (wave + NW * j) * 64 + lane;
+        const int kg = e / XW, t = e - kg * XW;
+        int pos = m0 - HL + t;
+        if (pos >= 0) xmask |= 1u << j;
+        pos = pos < 0 ? 0 : (pos >= a.Lin ? a.Lin - 1 : pos);
+        xvoff[j] = (unsigned)(((long)kg * a.x_cs + pos) * 16);
+    }
+    int issued = 0;                                 // vector-memory operations (DMA pieces) this wave has issued: wave-uniform
+    const unsigned long long xbase = reinterpret_cast<unsigned long long>(a.xb) + ((unsigned long long)((long)unit * a.x_us) << 4);
+    const unsigned long long xcb_bytes = (unsigned long long)a.x_cs * 64ull;
+    auto dma_x = [&](int cb, int buf) {
+        const unsigned long long base = xbase + (unsigned long long)cb * xcb_bytes;
+#pragma unroll
+        for (int j = 0; j < XP; j++)
+            if ((xmask >> j) & 1) rg_dma16(base, xvoff[j], x_lds + (unsigned)(buf * XBUF + (wave + NW * j) * 1024));
+        issued += XP;                               // (every piece has at least one lane inside the unit: HL < 64)
+    };
+    // weight pieces of this wave: piece wave + NW q covers the slot's elements 64 (wave + NW q) + lane = (k-group, row)
+    unsigned wvoff[WPMAX];
+#pragma unroll
+    for (int q = 0; q < WPMAX; q++) {
+        const int e = (wave + NW * q) * 64 + lane;
+        const int kg = e / BN, r = e - kg * BN;
+        wvoff[q] = (unsigned)(((long)(kg < 4 ? kg : 0) * a.NP + r) * 16);
+    }
+    const int wcount = (NPIECES - wave + NW - 1) / NW;            // pieces per slot of this wave (wave-uniform)
+    const unsigned long long wbase = reinterpret_cast<unsigned long long>(a.wb) + ((unsigned long long)n0 << 4);
+    const unsigned long long wkg_bytes = (unsigned long long)a.NP * 16ull;
+    auto dma_w = [&](int cb, int tap, int slot) {
+        const unsigned long long base = wbase + (unsigned long long)((tap * ncb + cb) * 4) * wkg_bytes;
+#pragma unroll
+        for (int q = 0; q < WPMAX; q++)
+            if (q < wcount) rg_dma16(base, wvoff[q], w_lds + (unsigned)(slot * SLOTB + (wave + NW * q) * 1024));
+        issued += wcount;
+    };
+
+    f32x16 acc[PT][TN];
+#pragma unroll
+    for (int p = 0; p < PT; p++)
+#pragma unroll
+        for (int i = 0; i < TN; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[p][i][r] = 0.0f;
+
+    // marks: `issued` right after the last piece of the tile in ring slot j / activation buffer j
+    int wmark[RW], xmark[2] = {0, 0};
+#pragma unroll
+    for (int j = 0; j < RW; j++) wmark[j] = 0;
+    dma_x(0, 0);
+    xmark[0] = issued;
+#pragma unroll
+    for (int j = 0; j < RW - 1; j++) {              // slots of stages 0 .. RW - 2 (stage j = (cb, tap) = (j / NTAPS, j % NTAPS))
+        if (j < nstage) { dma_w(j / NTAPS, j % NTAPS, j); wmark[j] = issued; }
+    }
+
+    const unsigned xaddr0 = x_lds + (unsigned)((h * XW + wave * 64 + l31 + HL + a.shift0) * 16);
+    const unsigned waddr0 = w_lds + (unsigned)((h * BN + l31) * 16);
+    const unsigned d16 = (unsigned)a.shift_step * 16u;
+
+    rg_bf16x8 bq[2][PT];
+    int slot = 0;                                   // ring slot of the current stage = stage mod RW
+    int cb3 = (RW - 1) / NTAPS, tap3 = (RW - 1) % NTAPS;          // (cb, tap) of the stage RW - 1 ahead
+    for (int cb = 0; cb < ncb; cb++) {
+#pragma unroll
+        for (int tap = 0; tap < NTAPS; tap++) {
+            // this wave's pieces of the stage's slot -- and, at tap 0, of the block's activation tile -- have landed: everything it
+            // issued after them may stay in flight; then every wave's
+            {
+                int need = 0;
+#pragma unroll
+                for (int j = 0; j < RW; j++) need = slot == j ? wmark[j] : need;
+                if (tap == 0) { const int xm = (cb & 1) ? xmark[1] : xmark[0]; need = xm > need ? xm : need; }
+                rg_wait_dyn(issued - need);
+                rg_wait_bar<63>();                  // (lgkmcnt(0) + barrier; the vmcnt part is the counted wait above)
+            }
+            // every wave is past the previous stage: its slot, and at tap 0 the other activation buffer, are free
+            if (cb3 < ncb) {
+                int fs = slot == 0 ? RW - 1 : slot - 1;
+                dma_w(cb3, tap3, fs);
+#pragma unroll
+                for (int j = 0; j < RW; j++) wmark[j] = fs == j ? issued : wmark[j];
+            }
+            if (++tap3 == NTAPS) { tap3 = 0; cb3++; }
+            if (tap == 0 && cb + 1 < ncb) {
+                dma_x(cb + 1, (cb + 1) & 1);
+                if ((cb + 1) & 1) xmark[1] = issued; else xmark[0] = issued;
+            }
+            const unsigned xa = xaddr0 + (unsigned)((cb & 1) * XBUF) + (unsigned)tap * d16;
+            const unsigned wa = waddr0 + (unsigned)(slot * SLOTB);
+            rg_bf16x8 aq[2][TN];
+            if (tap == 0 || !BNEXT) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+                    for (int p = 0; p < PT; p++) bq[ks][p] = rg_lds16(xa + (unsigned)(ks * 2 * XW * 16 + p * 512));
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+                for (int i = 0; i < TN; i++) aq[ks][i] = rg_lds16(wa + (unsigned)(ks * 2 * BN * 16 + i * 512));
+            rg_bf16x8 bn[BNEXT ? 2 : 1][PT];
+            if (BNEXT && tap + 1 < NTAPS) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+                    for (int p = 0; p < PT; p++) bn[ks][p] = rg_lds16(xa + d16 + (unsigned)(ks * 2 * XW * 16 + p * 512));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+                for (int i = 0; i < TN; i++)
+#pragma unroll
+                    for (int p = 0; p < PT; p++) acc[p][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[ks][i], bq[ks][p], acc[p][i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (BNEXT && tap + 1 < NTAPS) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+                    for (int p = 0; p < PT; p++) bq[ks][p] = bn[ks][p];
+            }
+            slot = slot + 1 == RW ? 0 : slot + 1;
+        }
+    }
+
+    float *yu = a.y ? a.y + (long)unit * a.y_us : nullptr;
+    const float *ru0 = launder_after(a.res, acc[PT - 1][TN - 1][15]);
+    const float *ru = ru0 ? ru0 + (long)unit * a.y_us : nullptr;
+    float *y2u0 = launder_after(a.y2, acc[PT - 1][TN - 1][15]);
+    float *y2u = y2u0 ? y2u0 + (long)unit * a.y_us : nullptr;
+    unsigned short *ybu0 = launder_after(a.yb, acc[PT - 1][TN - 1][15]);
+    unsigned short *ybu = ybu0 ? ybu0 + (((long)unit * a.y_us) << 3) : nullptr;
+    static_assert(PT == 2 && TN <= 6, "the epilogue below is written out for these");
+    if constexpr (EPI == 3) {
+        tconv_pt_epilogue<BN, TN>(a, acc[0], Pm, n0, h, m0 + wave * 64 + l31, yu, y2u, ybu);
+        tconv_pt_epilogue<BN, TN>(a, acc[1], Pm, n0, h, m0 + wave * 64 + 32 + l31, yu, y2u, ybu);
+    } else {
+        // (written out: left as loops, hipcc keeps them rolled -- the body is large -- and the accumulators move to scratch)
+#define RG_EPI(i_)                                                                                                                    \
+    if constexpr ((i_) < TN) {                                                                                                       \
+        conv_epilogue_tile<BN, false, EPI == 2>(a, acc[0][(i_) < TN ? (i_) : 0], Pm, n0, (i_)*32 + 4 * h, m0 + wave * 64 + l31, yu, ru, y2u, ybu);      \
+        conv_epilogue_tile<BN, false, EPI == 2>(a, acc[1][(i_) < TN ? (i_) : 0], Pm, n0, (i_)*32 + 4 * h, m0 + wave * 64 + 32 + l31, yu, ru, y2u, ybu); \
+    }
+        RG_EPI(0) RG_EPI(1) RG_EPI(2) RG_EPI(3) RG_EPI(4) RG_EPI(5)
+#undef RG_EPI
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // The same conv in ONE 8-wave workgroup of 512 positions per CU, with a ring of EIGHT weight slots (conv7_bf16_ring8_kernel).
 // Timing ablations of the 4-wave form on block 1 (4.02 ms per pass for its three layers): without the weight DMA 3.24, without
 // any DMA 3.05, and without barriers 2.96 -- a weight tile three stages ahead is issued ~1.5 us before its use, about the
@@ -440,9 +658,15 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 1 : 2)) void conv7_bf16_ring8_k
 static int ring_mode() {
     // (read per launch: the tests switch it within one process) 0 = off, 1 = the 4-wave form (default), 2 = the 8-wave form, which
     // measured SLOWER on MI355X (block 1's layers 4.06 -> 4.33 ms per pass, block 0's 2.87 -> 2.93): one workgroup per CU moves in
-    // lock-step again, and neither the deeper ring nor the halved weight traffic makes up for it
+    // lock-step again, and neither the deeper ring nor the halved weight traffic makes up for it; 3 = the 4-wave form through the
+    // general kernel (conv_bf16_ring_kernel<4,7,0,4>: counted waits through a switch and per-lane weight offsets cost it 9 % on these
+    // layers: 4.04 -> 4.41 and 2.90 -> 3.19 ms)
     const char *e = getenv("HIPVOC_BF16_RING");
     return e ? atoi(e) : 1;
+}
+static bool ring_tconv_enabled() {
+    const char *e = getenv("HIPVOC_BF16_RING_TCONV");      // the transposed convs on the ring kernel (0: conv_gemm_bf16_oi / _pt_kernel)
+    return e ? atoi(e) != 0 : true;
 }
 
 bool conv7_bf16_ring_selected(const ConvGemmArgs &a) {
@@ -454,18 +678,68 @@ bool conv7_bf16_ring_selected(const ConvGemmArgs &a) {
     return true;
 }
 
-const char *conv7_bf16_ring_kernel_name(const ConvGemmArgs &) {
-    return ring_mode() == 1 ? "conv7_bf16_ring_kernel<4>" : "conv7_bf16_ring8_kernel<4,8,2>";
+// the decoder blocks' transposed convs (kernel = 2 stride: two taps) with octet-interleaved (pm 2, tile height 4) or phase-tile
+// rows (pm 3, tile height = stride 3 / 5): what conv_gemm_bf16_oi_kernel / _pt_kernel run, and their host checks
+static bool tconv_ring_selected(const ConvGemmArgs &a) {
+    if (ring_mode() <= 0 || !ring_tconv_enabled()) return false;
+    if (!a.wb || !a.xb || a.wb2 || a.wbm || a.sn_a || a.S < 2 || a.ntaps != 2 || a.shift_step != 1 || a.in_elu || a.s2d > 1) return false;
+    if (a.shift0 < -1 || a.shift0 > 0 || a.res || a.rscale || a.act != ACT_NONE || (a.Cin % 32) || a.units < 1 || a.M < 1 || a.Lin < a.M) return false;
+    if ((long)a.x_cs * 16 * 5 >= 0x7fffffffL || a.N % a.S || a.NP < a.N) return false;
+    const int tn = detail::conv_gemm_launch_tn(a);
+    if (a.pm == 2) return tn == 4 && (a.S == 4 || a.S == 8) && a.N % (8 * a.S) == 0 && a.NP % 128 == 0 && !(a.y_cs & 1) && !(a.y_us & 1);
+    // (stride 3, block 3's: Cin = 192 is twelve stages in all, the launch is its epilogue -- 1.80 ms per pass on either kernel, so
+    // it stays where it was; measured on MI355X for the others, per pass: stride 8 0.80 -> 0.73 ms, 5 1.34 -> 0.98, 4 1.37 -> 1.29)
+    if (a.pm == 3) return tn == a.S && a.S == 5 && (a.N / a.S) % 32 == 0 && a.NP == a.N;
+    return false;
+}
+bool conv_bf16_ring_selected(const ConvGemmArgs &a) { return conv7_bf16_ring_selected(a) || tconv_ring_selected(a); }
+
+const char *conv_bf16_ring_kernel_name(const ConvGemmArgs &a) {
+    if (tconv_ring_selected(a)) return a.pm == 2 ? "conv_bf16_ring_kernel<4,2,2,4>" : "conv_bf16_ring_kernel<5,2,3,3>";
+    const int m = ring_mode();
+    return m == 1 ? "conv7_bf16_ring_kernel<4>" : (m == 2 ? "conv7_bf16_ring8_kernel<4,8,2>" : "conv_bf16_ring_kernel<4,7,0,4>");
 }
 
-hipError_t launch_conv7_bf16_ring(const ConvGemmArgs &a, hipStream_t s) {
+template <int TN, int NTAPS, int EPI, int RW>
+static hipError_t ring_launch_general(const ConvGemmArgs &a, int HL, hipStream_t s) {
+    using namespace ring;
+    const int tiles_per_unit = (a.M + BM - 1) / BM;
+    const int n_tiles = a.NP / (32 * TN);
+    const long grid = (long)tiles_per_unit * a.units * n_tiles;
+    if (grid > 0x7fffffffL) return hipErrorInvalidValue;
+    constexpr size_t lds = 4 * 32 * TN * 4 + 2 * XBUF + (size_t)RW * 4 * 32 * TN * 16;
+    static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
+    static std::atomic<bool> done[64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64 && !done[dev]) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_bf16_ring_kernel<TN, NTAPS, EPI, RW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        done[dev] = true;
+    }
+    hipLaunchKernelGGL((conv_bf16_ring_kernel<TN, NTAPS, EPI, RW>), dim3((unsigned)grid), dim3(NTH), lds, s, a, HL, tiles_per_unit, n_tiles);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv_bf16_ring(const ConvGemmArgs &a, hipStream_t s) {
     constexpr int TN = 4;
-    if (!conv7_bf16_ring_selected(a)) return hipErrorInvalidValue;
     // host-side shape checks: what the kernels' indexing and vector accesses assume
-    if (((uintptr_t)a.wb & 15) || ((uintptr_t)a.xb & 15) || (a.yb && ((uintptr_t)a.yb & 15)) || (!a.y && !a.yb) || (a.yb && (a.N & 7)) ||
+    if (((uintptr_t)a.wb & 15) || ((uintptr_t)a.xb & 15) || (a.yb && ((uintptr_t)a.yb & 15)) || (!a.y && !a.yb) || (a.yb && ((a.N / a.S) & 7)) ||
         (a.y2 && (!a.psn_a || !a.psn_ib || a.yb)) || a.NP < a.N)
         return hipErrorInvalidValue;
-    const bool w8 = ring_mode() != 1;
+    if (tconv_ring_selected(a)) {
+        const int HL = a.shift0 < 0 ? -a.shift0 : 0;                   // taps at q + shift0, q + shift0 + 1: one position of halo, left or right
+        if (a.pm == 2) {
+            if ((a.y && ((uintptr_t)a.y & 7)) || (a.y2 && ((uintptr_t)a.y2 & 7))) return hipErrorInvalidValue;
+            return ring_launch_general<4, 2, 2, 4>(a, HL, s);
+        }
+        return ring_launch_general<5, 2, 3, 3>(a, HL, s);
+    }
+    if (!conv7_bf16_ring_selected(a)) return hipErrorInvalidValue;
+    const int mode = ring_mode();
+    if (mode >= 3) return ring_launch_general<4, 7, 0, 4>(a, -a.shift0, s);
+    const bool w8 = mode == 2;
     const int bm = w8 ? ring8::BM : ring::BM;
     const int tiles_per_unit = (a.M + bm - 1) / bm;
     const int n_tiles = a.NP / (32 * TN);

@@ -295,3 +295,39 @@ def test_bf16_conv7_ring_kernel_bitwise(pkg, synth, unit, frames, n_seq, monkeyp
         for a, b in zip(outs[0], other):
             assert a.size == b.size and a.size > 0
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), float(np.abs(a - b).max())
+
+
+@pytest.mark.parametrize("trim_right,unit,frames,n_seq", [(False, 64, 125, 1), (False, 64, 64, 9), (False, 5, 13, 50), (True, 64, 125, 2), (True, 3, 11, 70)])
+def test_bf16_ring_kernel_general_form_bitwise(pkg, synth, trim_right, unit, frames, n_seq, monkeypatch):
+    """bf16 mode: conv_bf16_ring_kernel<TN, NTAPS, EPI, RW> (kernels_bf16_ring.hip: the 4-wave ring kernel with counted waits, any
+    tile height) on the transposed convs of blocks 0 - 2 -- octet-interleaved rows (strides 8 and 4) and phase-tile rows
+    (stride 5: tile height 5, three weight slots) -- and on the conv7 layers (HIPVOC_BF16_RING=3),
+    against conv_gemm_bf16_oi / _pt_kernel and conv_gemm_bf16_kernel: the same MFMA chains and epilogues, so the same bits.
+    Both trim policies: the right-only one reads one position LEFT of each output (causal zero padding in the first tile), the
+    default one position to the right.  HIPVOC_CONVS_WGS=0 keeps the small-launch conv7 kernel out of the way."""
+    import dataclasses
+    cfg = dataclasses.replace(synth.FULL, transconv_trim_right_only=True) if trim_right else synth.FULL
+    path = os.path.join(tempfile.gettempdir(), f"hipvoc_test_FULL_0{'_trimr' if trim_right else ''}.safetensors")
+    if not os.path.exists(path):
+        synth.save_safetensors(path, weights_for(synth, "FULL", 0), cfg.metadata())
+    seqs = [synth.make_codes(frames, 277 + i, cfg) for i in range(n_seq)]
+    monkeypatch.setenv("HIPVOC_CONVS_WGS", "0")
+    outs = []
+    for ring, tc in (("0", "0"), ("3", "1")):
+        monkeypatch.setenv("HIPVOC_BF16_RING", ring)              # read at every launch
+        monkeypatch.setenv("HIPVOC_BF16_RING_TCONV", tc)
+        v = pkg.HipVocoder.load(path, device=0, unit_frames=unit, dtype=BF16)
+        assert v.unit_samples == (unit * 1920 if trim_right else unit * 1920 - 555)
+        v.set_profile(True)
+        outs.append(v.synthesize_batch(seqs))
+        used = sorted(k.split("|")[1] for k in v.last_profile() if "conv_bf16_ring_kernel" in k)
+        want = ["conv_bf16_ring_kernel<4,2,2,4>", "conv_bf16_ring_kernel<4,2,2,4>", "conv_bf16_ring_kernel<4,7,0,4>",
+                "conv_bf16_ring_kernel<4,7,0,4>", "conv_bf16_ring_kernel<5,2,3,3>"] if ring != "0" else []
+        if (unit < 64 or len(seqs) * ((frames + unit - 1) // unit) < 9) and want:      # (small launches: the first blocks' trans-convs run at a lowered tile height, on the old kernels)
+            assert set(used) >= {"conv_bf16_ring_kernel<4,7,0,4>"} and set(used) <= set(want), (ring, sorted(v.last_profile()))
+        else:
+            assert used == want, (ring, sorted(v.last_profile()))
+        del v
+    for a, b in zip(*outs):
+        assert a.size == b.size and a.size > 0
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), float(np.abs(a - b).max())
