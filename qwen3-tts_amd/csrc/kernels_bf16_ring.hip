@@ -465,6 +465,238 @@ __global__ __launch_bounds__(ring::NTH, 2) void conv_bf16_ring_kernel(ConvGemmAr
 }
 
 // ---------------------------------------------------------------------------------------------------
+// A whole residual unit of a 192-channel block (block 2) on the ring (resunit_bf16_ring_kernel<6>):
+//     y = x + W2 snake2(conv7_dil(xb) + b1) + b2      (xb = snake1(x), packed, written by the producer)
+// conv_gemm_bf16_kernel<6,true,true> runs it in ONE 8-wave workgroup of 256 positions per CU: barrier -> operand reads -> twelve
+// MFMAs -> register-staged weight commit in lock-step, then an epilogue (two SnakeBeta evaluations per element, the 1x1 conv with
+// a barrier per output tile, residual loads, stores) that nothing overlaps -- matrix pipe busy 32 % of the cycles, 46 % of all
+// wave cycles parked (profiles/r03_pmc_sq_bf16.txt).  Here: 4-wave workgroups of 128 positions (a wave = 192 rows x 32 positions,
+// six accumulator tiles), 77 KB of LDS, so TWO independent workgroups share a CU and one's epilogue runs under the other's main
+// loop; weights by LDS-DMA three stages ahead through four 12 KB slots -- the six output tiles of the 1x1 conv's weights simply
+// follow the conv7's 42 tiles in the same stream of slots -- activation tile double-buffered.  (The 4-wave shape was tried with
+// register-staged weights in round 3 and lost 5 %: twice the staging instructions per position.  The DMA issues no such
+// instructions; what doubles is L2 -> LDS traffic.)  Per output element the MFMA chains, SnakeBeta evaluations, roundings and
+// the residual add are conv_gemm_bf16_kernel<6,true,true>'s: bit-identical (tests/test_gpu_bf16.py).
+namespace ringu {
+constexpr int NW = 4, NTH = 64 * NW, BM = 32 * NW;                  // one 32-position tile per wave
+constexpr int XW = 192;                     // BM + the left halo (<= 64)
+constexpr int XBUF = 4 * XW * 16;
+constexpr int XP = 4 * XW / 64 / NW;        // 3 pieces per wave and activation tile
+constexpr int RW = 4;
+constexpr int NTAPS = 7;
+static_assert(4 * XW % (64 * NW) == 0, "every wave issues the same number of activation pieces");
+}  // namespace ringu
+
+template <int TN>
+__global__ __launch_bounds__(ringu::NTH, 2) void resunit_bf16_ring_kernel(ConvGemmArgs a, int tiles_per_unit) {
+    using namespace ringu;
+    constexpr int BN = 32 * TN;
+    constexpr int SLOTB = 4 * BN * 16;              // conv7 slot [4 k-groups][BN rows]; also one output tile of the 1x1 conv: [2 TN k-steps][64 lanes]
+    constexpr int WP = SLOTB / 1024 / NW;
+    static_assert(SLOTB % (1024 * NW) == 0 && 2 * TN * 64 * 16 == SLOTB, "whole pieces per wave; a 1x1 tile fills a slot");
+    constexpr int PMB = 6 * BN * 4;                 // fused parameter table (device_common.h)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *Pm = reinterpret_cast<float *>(smem);
+    uint4 *Xs = reinterpret_cast<uint4 *>(smem + PMB);
+    const unsigned x_lds = (unsigned)(size_t)(rg_lptr_t)(smem + PMB);
+    const unsigned w_lds = x_lds + 2 * XBUF;
+
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+    const int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    const int unit = id / tiles_per_unit;
+    const int m0 = (id - unit * tiles_per_unit) * BM;
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int d = a.shift_step, HL = -a.shift0;     // (host: HL == 6 d <= 64)
+    const int ncb = a.Cin / 32;
+    const int nstage = ncb * NTAPS;
+
+    fill_param_table<BN, true>(a, Pm, 0, tid, NTH);
+    if (m0 == 0) {
+        for (int e = tid; e < 2 * 4 * HL; e += NTH) {
+            const int row = e / HL, t = e - row * HL;
+            Xs[row * XW + t] = make_uint4(0, 0, 0, 0);
+        }
+    }
+    unsigned xvoff[XP];
+    unsigned xmask = 0;
+#pragma unroll
+    for (int j = 0; j < XP; j++) {
+        const int e = (wave + NW * j) * 64 + lane;
+        const int kg = e / XW, t = e - kg * XW;
+        int pos = m0 - HL + t;
+        if (pos >= 0) xmask |= 1u << j;
+        pos = pos < 0 ? 0 : (pos >= a.Lin ? a.Lin - 1 : pos);
+        xvoff[j] = (unsigned)(((long)kg * a.x_cs + pos) * 16);
+    }
+    const unsigned long long xbase = reinterpret_cast<unsigned long long>(a.xb) + ((unsigned long long)((long)unit * a.x_us) << 4);
+    const unsigned long long xcb_bytes = (unsigned long long)a.x_cs * 64ull;
+    auto dma_x = [&](int cb, int buf) {
+        if ((RG_ABL & 2) && cb > 0) return;
+        const unsigned long long base = xbase + (unsigned long long)cb * xcb_bytes;
+#pragma unroll
+        for (int j = 0; j < XP; j++)
+            if ((xmask >> j) & 1) rg_dma16(base, xvoff[j], x_lds + (unsigned)(buf * XBUF + (wave + NW * j) * 1024));
+    };
+    // the weight stream: stages 0 .. nstage - 1 are the conv7's (cb, tap) slots [4][NP] (NP == BN: contiguous), stages
+    // nstage .. nstage + TN - 1 the output tiles of the 1x1 conv (ConvGemmArgs::wb2: [TN tiles][2 TN k-steps][64 lanes], SLOTB each)
+    const unsigned long long wbase = reinterpret_cast<unsigned long long>(a.wb);
+    const unsigned long long w2base = reinterpret_cast<unsigned long long>(a.wb2);
+    const unsigned wlane = (unsigned)lane * 16u;
+    auto dma_w = [&](int st, int slot) {            // (st < nstage + TN: caller)
+        if ((RG_ABL & 1) && st > 2) return;
+        unsigned long long base;
+        if (st < nstage) {
+            const int cb = st / NTAPS, tap = st - cb * NTAPS;
+            base = wbase + (unsigned long long)(tap * ncb + cb) * SLOTB;
+        } else {
+            base = w2base + (unsigned long long)(st - nstage) * SLOTB;
+        }
+#pragma unroll
+        for (int q = 0; q < WP; q++) rg_dma16(base + (unsigned long long)((wave * WP + q) * 1024), wlane, w_lds + (unsigned)(slot * SLOTB + (wave * WP + q) * 1024));
+    };
+
+    f32x16 acc[TN];
+#pragma unroll
+    for (int i = 0; i < TN; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][r] = 0.0f;
+
+    dma_x(0, 0);
+    dma_w(0, 0);
+    dma_w(1, 1);
+    dma_w(2, 2);
+
+    const unsigned xaddr0 = x_lds + (unsigned)((h * XW + wave * 32 + l31) * 16);
+    const unsigned waddr0 = w_lds + (unsigned)((h * BN + l31) * 16);
+    const unsigned d16 = (unsigned)d * 16u;
+
+    // The barrier at the top of stage st certifies the slot of stage st + 1 (each wave waits for its own pieces of THAT slot
+    // first), so the operands of k-step (st + 1, 0) can be read during the MFMAs of k-step (st, 1), across the barrier: no MFMA
+    // waits for an LDS read issued behind the barrier it follows.  Two operand sets alternate per k-step.
+    rg_bf16x8 aq[2][TN], bq[2];
+#define RU_READ(set_, xa_, wa_, ks_)                                                                                \
+    {                                                                                                               \
+        bq[set_] = rg_lds16((xa_) + (unsigned)((ks_)*2 * XW * 16));                                                 \
+        _Pragma("unroll") for (int i = 0; i < TN; i++) aq[set_][i] = rg_lds16((wa_) + (unsigned)((ks_)*2 * BN * 16 + i * 512)); \
+    }
+#define RU_MFMA(set_)                                                                                               \
+    { _Pragma("unroll") for (int i = 0; i < TN; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[set_][i], bq[set_], acc[i], 0, 0, 0); }
+    rg_wait_bar<2 * WP>();                          // slot 0 and the first activation tile (younger: slots 1, 2)
+    RU_READ(0, xaddr0, waddr0, 0)
+    for (int cb = 0; cb < ncb; cb++) {
+        const bool lastcb = cb + 1 == ncb;
+#pragma unroll
+        for (int tap = 0; tap < NTAPS; tap++) {
+            const int st = cb * NTAPS + tap, slot = st & (RW - 1);
+            // slot st + 1 (issued two stages ago; the 1x1 conv's tiles continue the stream, so it always exists): younger are the
+            // slot of stage st + 2 and, during taps 1-2, the next block's activation tile (issued at tap 0, behind that stage's slot)
+            if (!lastcb && tap >= 1 && tap <= 2) rg_wait_bar<WP + XP>();
+            else rg_wait_bar<WP>();
+            // every wave is past stage st - 1 (whose operands it read before this barrier): that slot, and at tap 0 the other
+            // activation buffer, are free
+            dma_w(st + 3, (st + 3) & (RW - 1));     // (st + 3 <= nstage + 2 < nstage + TN)
+            if (tap == 0 && !lastcb) dma_x(cb + 1, (cb + 1) & 1);
+            const unsigned xa = xaddr0 + (unsigned)((cb & 1) * XBUF) + (unsigned)tap * d16;
+            const unsigned wa = waddr0 + (unsigned)(slot * SLOTB);
+            RU_READ(1, xa, wa, 1)
+            __builtin_amdgcn_sched_barrier(0);
+            RU_MFMA(0)
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(lastcb && tap == NTAPS - 1)) {    // k-step (st + 1, 0): the next tap of this tile, or tap 0 of the next block's
+                const unsigned xa1 = tap + 1 < NTAPS ? xa + d16 : xaddr0 + (unsigned)(((cb + 1) & 1) * XBUF);
+                const unsigned wa1 = waddr0 + (unsigned)(((st + 1) & (RW - 1)) * SLOTB);
+                RU_READ(0, xa1, wa1, 0)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            RU_MFMA(1)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#undef RU_READ
+#undef RU_MFMA
+
+    const int m = m0 + wave * 32 + l31;
+    // the residual of output tile o: sixteen unconditional loads from a clamped position (N == BN: every row exists), requested one
+    // tile AHEAD; tile 0's before the SnakeBeta pass below
+    const float *rup = a.res + (long)unit * a.y_us + (m < a.M ? m : a.M - 1) + (long)(4 * h) * a.y_cs;
+    auto fetch_res = [&](int o, float *dst) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) dst[r] = rup[(long)(o * 32 + (r & 3) + 8 * (r >> 2)) * a.y_cs];
+    };
+    float resv[2][16];
+    fetch_res(0, resv[0]);
+    // the first output tile's weights (slot nstage: certified by the last stage's barrier) are read under the SnakeBeta pass too
+    const unsigned w2addr0 = w_lds + (unsigned)lane * 16u;
+    rg_bf16x8 w2q[2][2 * TN];
+#pragma unroll
+    for (int k = 0; k < 2 * TN; k++) w2q[0][k] = rg_lds16(w2addr0 + (unsigned)((nstage & (RW - 1)) * SLOTB + k * 1024));
+    // ---- H = snake2(acc + b1) -> the 1x1 conv's bf16 B operands: a lane's registers 8g .. 8g+7 of tile i are its eight k of k-step 2i + g
+    rg_bf16x8 hb[TN][2];
+#pragma unroll
+    for (int i = 0; i < TN; i++) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int n = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (r & 1) {
+                f32x2 hv = snake_beta2(mk2(acc[i][r - 1] + Pm[n - 1], acc[i][r] + Pm[n]), mk2(Pm[BN + n - 1], Pm[BN + n]),
+                                       mk2(Pm[2 * BN + n - 1], Pm[2 * BN + n]));
+                acc[i][r - 1] = hv.x;
+                acc[i][r] = hv.y;
+            }
+            if ((r & 3) == 3) {
+                asm volatile("" : "+v"(acc[i][r - 3]), "+v"(acc[i][r - 2]), "+v"(acc[i][r - 1]), "+v"(acc[i][r]));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 2; g++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) hb[i][g][j] = (__bf16)acc[i][8 * g + j];
+    }
+    float *yu = a.y ? a.y + (long)unit * a.y_us : nullptr;
+    unsigned short *ybu = a.yb ? a.yb + (((long)unit * a.y_us) << 3) : nullptr;
+#pragma unroll
+    for (int o = 0; o < TN; o++) {
+        const int st = nstage + o;
+        // certify the next tile's slot (younger: the tile after it -- and, unknown to this count, residual loads: the smaller
+        // immediate only waits for them too); then that slot of the ring is everybody's to read, and tile o - 1's is free
+        asm volatile("" ::: "memory");
+        if (o + 2 < TN) rg_wait_bar<WP>();
+        else rg_wait_bar<0>();
+        if (o + 3 < TN) dma_w(st + 3, (st + 3) & (RW - 1));
+        if (o + 1 < TN) fetch_res(o + 1, resv[(o + 1) & 1]);
+        asm volatile("" ::: "memory");
+        if (o + 1 < TN) {
+#pragma unroll
+            for (int k = 0; k < 2 * TN; k++) w2q[(o + 1) & 1][k] = rg_lds16(w2addr0 + (unsigned)(((st + 1) & (RW - 1)) * SLOTB + k * 1024));
+        }
+        f32x16 acc2;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc2[r] = 0.0f;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TN; i++)
+#pragma unroll
+            for (int g = 0; g < 2; g++) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2q[o & 1][i * 2 + g], hb[i][g], acc2, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        fused_epilogue_tile<BN>(a, acc2, resv[o & 1], Pm, o * 32 + 4 * h, m, yu, ybu);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Measured out for the residual unit (all bit-identical; block 2's three units per 64-unit pass on MI355X): TWO position tiles per
+// wave (192 rows x 64 positions, 192 accumulator registers, 256 positions per workgroup, three weight slots and an activation tile
+// of exactly 312 positions so that two workgroups still fit a CU): half the operand reads per MFMA and half the L2 -> LDS weight
+// traffic, but operands single-buffered per k-step and 77 registers spilled around the SnakeBeta pass -- 6.57 ms against 6.26
+// (its floor without DMA, barriers and operand reads: 5.05 ms against 4.55).  Timing ablations of the kernel above: without the
+// weight DMA 5.00 ms, without the LDS operand reads 4.97, without barriers 6.24, without all three 4.55; reading the operands of
+// k-step (st + 1, 0) across the barrier (the certify-ahead form it has now) moved 6.26 to 6.18: what the DMA and the operand reads
+// cost is LDS and L2 bandwidth next to each other (13 GB of slots per launch: 6.3 TB/s), not exposed latency.
+
+// ---------------------------------------------------------------------------------------------------
 // The same conv in ONE 8-wave workgroup of 512 positions per CU, with a ring of EIGHT weight slots (conv7_bf16_ring8_kernel).
 // Timing ablations of the 4-wave form on block 1 (4.02 ms per pass for its three layers): without the weight DMA 3.24, without
 // any DMA 3.05, and without barriers 2.96 -- a weight tile three stages ahead is issued ~1.5 us before its use, about the
@@ -692,9 +924,23 @@ static bool tconv_ring_selected(const ConvGemmArgs &a) {
     if (a.pm == 3) return tn == a.S && a.S == 5 && (a.N / a.S) % 32 == 0 && a.NP == a.N;
     return false;
 }
-bool conv_bf16_ring_selected(const ConvGemmArgs &a) { return conv7_bf16_ring_selected(a) || tconv_ring_selected(a); }
+static int ring_unit_mode() {
+    const char *e = getenv("HIPVOC_BF16_RING_UNIT");       // (read per launch) 0: conv_gemm_bf16_kernel<6,true,true>
+    return e ? atoi(e) : 1;
+}
+// the fused residual unit of a 192-channel block (what conv_gemm_bf16_kernel<6,true,true> runs, and its host checks)
+static bool resunit_ring_selected(const ConvGemmArgs &a) {
+    if (ring_mode() <= 0 || ring_unit_mode() == 0) return false;
+    if (!a.wb || !a.wb2 || !a.xb || a.wbm || a.sn_a || a.S != 1 || a.ntaps != ringu::NTAPS || a.in_elu || a.s2d > 1 || a.act != ACT_NONE || a.rscale || a.y2) return false;
+    if (a.shift_step < 1 || a.shift0 != -6 * a.shift_step || -a.shift0 > 64) return false;
+    if (a.N != 192 || a.NP != 192 || a.Cin != 192 || !a.res || !a.bias || !a.bias2 || !a.sn2_a || !a.sn2_ib || a.units < 1 || a.M < 1 || a.Lin < a.M) return false;
+    if ((long)a.x_cs * 16 * 5 >= 0x7fffffffL) return false;
+    return true;
+}
+bool conv_bf16_ring_selected(const ConvGemmArgs &a) { return conv7_bf16_ring_selected(a) || tconv_ring_selected(a) || resunit_ring_selected(a); }
 
 const char *conv_bf16_ring_kernel_name(const ConvGemmArgs &a) {
+    if (resunit_ring_selected(a)) return "resunit_bf16_ring_kernel<6>";
     if (tconv_ring_selected(a)) return a.pm == 2 ? "conv_bf16_ring_kernel<4,2,2,4>" : "conv_bf16_ring_kernel<5,2,3,3>";
     const int m = ring_mode();
     return m == 1 ? "conv7_bf16_ring_kernel<4>" : (m == 2 ? "conv7_bf16_ring8_kernel<4,8,2>" : "conv_bf16_ring_kernel<4,7,0,4>");
@@ -728,6 +974,26 @@ hipError_t launch_conv_bf16_ring(const ConvGemmArgs &a, hipStream_t s) {
     if (((uintptr_t)a.wb & 15) || ((uintptr_t)a.xb & 15) || (a.yb && ((uintptr_t)a.yb & 15)) || (!a.y && !a.yb) || (a.yb && ((a.N / a.S) & 7)) ||
         (a.y2 && (!a.psn_a || !a.psn_ib || a.yb)) || a.NP < a.N)
         return hipErrorInvalidValue;
+    if (resunit_ring_selected(a)) {
+        using namespace ringu;
+        if (((uintptr_t)a.wb2 & 15) || (a.yb && !a.psn_a) || (a.psn_a && !a.psn_ib)) return hipErrorInvalidValue;
+        const int tiles_per_unit = (a.M + BM - 1) / BM;
+        const long grid = (long)tiles_per_unit * a.units;
+        if (grid > 0x7fffffffL) return hipErrorInvalidValue;
+        constexpr size_t lds = 6 * 192 * 4 + 2 * XBUF + (size_t)RW * 4 * 192 * 16;
+        static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
+        static std::atomic<bool> doneu[64] = {};
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64 && !doneu[dev]) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(resunit_bf16_ring_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            doneu[dev] = true;
+        }
+        hipLaunchKernelGGL(resunit_bf16_ring_kernel<6>, dim3((unsigned)grid), dim3(NTH), lds, s, a, tiles_per_unit);
+        return hipGetLastError();
+    }
     if (tconv_ring_selected(a)) {
         const int HL = a.shift0 < 0 ? -a.shift0 : 0;                   // taps at q + shift0, q + shift0 + 1: one position of halo, left or right
         if (a.pm == 2) {

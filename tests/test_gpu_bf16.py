@@ -331,3 +331,29 @@ def test_bf16_ring_kernel_general_form_bitwise(pkg, synth, trim_right, unit, fra
     for a, b in zip(*outs):
         assert a.size == b.size and a.size > 0
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), float(np.abs(a - b).max())
+
+
+@pytest.mark.parametrize("unit,frames,n_seq", [(64, 125, 1), (64, 64, 9), (7, 33, 40), (2, 7, 64)])
+def test_bf16_resunit_ring_kernel_bitwise(pkg, synth, unit, frames, n_seq, monkeypatch):
+    """bf16 mode, block 2 (192 channels): the whole residual unit on the ring (kernels_bf16_ring.hip: 4-wave workgroups, two per CU,
+    conv7 and 1x1-conv weights as one stream of LDS-DMA slots: resunit_bf16_ring_kernel<6>, 128 positions per workgroup) against
+    conv_gemm_bf16_kernel<6,true,true> (HIPVOC_BF16_RING_UNIT=0): the same MFMA chains, SnakeBeta evaluations, roundings and
+    residual add per output element, so the same bits -- a lone utterance, a full pass, passes of many short units."""
+    cfg = synth.FULL
+    path = os.path.join(tempfile.gettempdir(), "hipvoc_test_FULL_0.safetensors")
+    if not os.path.exists(path):
+        synth.save_safetensors(path, weights_for(synth, "FULL", 0), cfg.metadata())
+    seqs = [synth.make_codes(frames, 377 + i, cfg) for i in range(n_seq)]
+    outs = []
+    for mode, name in (("0", None), ("1", "resunit_bf16_ring_kernel<6>")):
+        monkeypatch.setenv("HIPVOC_BF16_RING_UNIT", mode)         # read at every launch
+        v = pkg.HipVocoder.load(path, device=0, unit_frames=unit, dtype=BF16)
+        v.set_profile(True)
+        outs.append(v.synthesize_batch(seqs))
+        used = [k for k in v.last_profile() if "resunit_bf16_ring" in k]
+        assert used == ([f"b2_resunit|{name}"] if name else []), (mode, sorted(v.last_profile()))
+        del v
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert a.size == b.size and a.size > 0
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), float(np.abs(a - b).max())

@@ -36,6 +36,17 @@ if [ "$what" = stats ] || [ "$what" = all ]; then
   tools/prof_sq_one.sh bf16 bf16_r03 || exit 1
   cp $O/sq_f32_r03.txt $D/r03_pmc_sq_f32.txt; cp $O/sq_bf16_r03.txt $D/r03_pmc_sq_bf16.txt
   echo sq done
+  # the clock the chip holds under each kernel (GRBM_GUI_ACTIVE / 8 / duration)
+  cd /tmp
+  for leg in f32:profile_steps.py bf16:bf16_steps.py; do
+    name=${leg%%:*}; script=${leg##*:}
+    rm -rf $O/prof_clk_$name
+    timeout -s KILL 300 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $O/prof_clk_$name -o clk -- python3 $R/tools/$script > $O/clk_$name.out 2>&1 || exit 1
+    python3 $R/tools/pmc_clock.py $O/prof_clk_$name/clk_counter_collection.csv > $D/r03_pmc_clock_$name.txt || exit 1
+    rm -rf $O/prof_clk_$name
+  done
+  cd $R
+  echo clock done
 fi
 if [ "$what" = bench ] || [ "$what" = all ]; then
   cd $R
