@@ -254,6 +254,7 @@ def test_bf16_fused_units_in_4_wave_workgroups_bitwise(pkg, synth, cfg_name, uni
         synth.save_safetensors(path, weights_for(synth, cfg_name, 0), cfg.metadata())
     codes = synth.make_codes(frames, 41, cfg)
     monkeypatch.setenv("HIPVOC_BLK3", "0")
+    monkeypatch.setenv("HIPVOC_BF16_RING_UNIT", "0")              # (block 2's units otherwise run on resunit_bf16_ring_kernel)
     outs = []
     for w4 in ("0", "1"):
         monkeypatch.setenv("HIPVOC_BF16_W4", w4)                  # read at every launch
