@@ -93,6 +93,25 @@ __device__ __forceinline__ f32x2 snake_beta2(f32x2 x, f32x2 ea, f32x2 ib) {
     return fma2(ib, sin_sq2(x * ea), x);
 #endif
 }
+// bf16 conv-GEMM mode only (FAST): sin^2 by the hardware's v_sin_f32 (argument in revolutions, after v_fract_f32) instead of the
+// polynomial: 4 packed + 4 scalar instructions per PAIR of values against 14 packed ones.  Its sin^2 is good to 7e-6 for |t| < 100
+// (tools/ubench/vsin_err.hip) -- three orders of magnitude under the mode's own bf16 rounding of every operand (2^-9 relative) and
+// of no consequence for its stated tolerance, but NOT good enough for the fp32 gates: the fp32 and bf16x3 modes keep the polynomial.
+// Every kernel of the bf16 mode uses this one form (staging-side, fused and epilogue activations alike), so batch == single and the
+// bitwise tests between kernel shapes hold as before.  HIPVOC_SNAKE_HW=0 at compile time restores the polynomial everywhere.
+#ifndef HIPVOC_SNAKE_HW
+#define HIPVOC_SNAKE_HW 1
+#endif
+__device__ __forceinline__ f32x2 snake_beta2_hw(f32x2 x, f32x2 ea, f32x2 ib) {
+    const f32x2 rev = (x * ea) * 0.15915494309189535f;
+    const float s0 = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(rev.x)), s1 = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(rev.y));
+    return fma2(ib, mk2(s0 * s0, s1 * s1), x);
+}
+template <bool FAST>
+__device__ __forceinline__ f32x2 snake_beta2_t(f32x2 x, f32x2 ea, f32x2 ib) {
+    if constexpr (FAST && HIPVOC_SNAKE_HW) return snake_beta2_hw(x, ea, ib);
+    else return snake_beta2(x, ea, ib);
+}
 __device__ __forceinline__ float snake_beta(float x, float ea, float ib) {
     f32x2 v = snake_beta2((f32x2)(x), (f32x2)(ea), (f32x2)(ib));
     return v.x;
@@ -167,7 +186,7 @@ __device__ __forceinline__ uint2 pack4_bf16(float a, float b, float c, float d) 
 // (channel, phase) pairs the bf16 values go out one by one.
 // Epilogue of one 32-row tile with octet-interleaved rows (pm == 2; the decoder blocks' transposed convs: bias, optional SnakeBeta
 // to y / y2 / the packed tensor -- no residual, scale or activation, which the host checks).
-template <int BN>
+template <int BN, bool FAST = false>
 __device__ __forceinline__ void tconv_oi_epilogue_tile(const ConvGemmArgs &a, const f32x16 &acc, const float *Pm, int n0, int rbase, int m,
                                                        float *yu, float *y2u, unsigned short *ybu) {
     const int S = a.S, h = (rbase >> 2) & 1, nb = n0 + (rbase & ~31);
@@ -185,7 +204,7 @@ __device__ __forceinline__ void tconv_oi_epilogue_tile(const ConvGemmArgs &a, co
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {                       // registers r, r + 1: one channel, two phases
             const int row = rbase + (r & 3) + 8 * (r >> 2);
-            const f32x2 sv = snake_beta2(mk2(v[r], v[r + 1]), mk2(Pm[2 * BN + row], Pm[2 * BN + row + 1]), mk2(Pm[3 * BN + row], Pm[3 * BN + row + 1]));
+            const f32x2 sv = snake_beta2_t<FAST>(mk2(v[r], v[r + 1]), mk2(Pm[2 * BN + row], Pm[2 * BN + row + 1]), mk2(Pm[3 * BN + row], Pm[3 * BN + row + 1]));
             w[r] = sv.x; w[r + 1] = sv.y;
         }
     }
@@ -220,7 +239,7 @@ __device__ __forceinline__ void tconv_oi_epilogue_tile(const ConvGemmArgs &a, co
 // holds its other phases in the same register of the other tiles: S consecutive floats of y (4-byte stores that tile whole lines
 // across the wave and the S store instructions), and for the packed tensor the 8-byte halves (four channels) of S adjacent
 // elements.  Needs the launch's tile height to be S (detail::conv_gemm_launch_tn).
-template <int BN, int S>
+template <int BN, int S, bool FAST = false>
 __device__ __forceinline__ void tconv_pt_epilogue(const ConvGemmArgs &a, const f32x16 (&acc)[S], const float *Pm, int n0, int h, int m,
                                                   float *yu, float *y2u, unsigned short *ybu) {
     static_assert(BN == 32 * S, "one row tile per phase");
@@ -246,7 +265,7 @@ __device__ __forceinline__ void tconv_pt_epilogue(const ConvGemmArgs &a, const f
 #pragma unroll
                 for (int j = 0; j < 4; j += 2) {
                     const int row = ph * 32 + 8 * g + 4 * h + j;
-                    const f32x2 sv = snake_beta2(mk2(v[ph][j], v[ph][j + 1]), mk2(Pm[2 * BN + row], Pm[2 * BN + row + 1]), mk2(Pm[3 * BN + row], Pm[3 * BN + row + 1]));
+                    const f32x2 sv = snake_beta2_t<FAST>(mk2(v[ph][j], v[ph][j + 1]), mk2(Pm[2 * BN + row], Pm[2 * BN + row + 1]), mk2(Pm[3 * BN + row], Pm[3 * BN + row + 1]));
                     w[ph][j] = sv.x; w[ph][j + 1] = sv.y;
                 }
         }
@@ -273,11 +292,11 @@ __device__ __forceinline__ void tconv_pt_epilogue(const ConvGemmArgs &a, const f
 
 // OI: the kernel instance for octet-interleaved transposed convs (pm == 2).  A compile-time choice: as a run-time branch the second
 // epilogue cost the 128-register bf16 kernels spills in every layer (measured: conv7 layers 8x slower).
-template <int BN, bool ENC = false, bool OI = false>
+template <int BN, bool ENC = false, bool OI = false, bool FAST = false>
 __device__ __forceinline__ void conv_epilogue_tile(const ConvGemmArgs &a, const f32x16 &acc, const float *Pm, int n0, int rbase,
                                                    int m, float *yu, const float *ru, float *y2u, unsigned short *ybu = nullptr) {
     if constexpr (OI) {
-        tconv_oi_epilogue_tile<BN>(a, acc, Pm, n0, rbase, m, yu, y2u, ybu);
+        tconv_oi_epilogue_tile<BN, FAST>(a, acc, Pm, n0, rbase, m, yu, y2u, ybu);
         return;
     }
 #pragma unroll
@@ -367,7 +386,7 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvGemmArgs &a, const 
             if (a.psn_a) {
 #pragma unroll
                 for (int q = 0; q < 8; q += 2) {
-                    f32x2 sv = snake_beta2(mk2(v[q], v[q + 1]), mk2(Pm[2 * BN + row[q]], Pm[2 * BN + row[q + 1]]),
+                    f32x2 sv = snake_beta2_t<FAST>(mk2(v[q], v[q + 1]), mk2(Pm[2 * BN + row[q]], Pm[2 * BN + row[q + 1]]),
                                            mk2(Pm[3 * BN + row[q]], Pm[3 * BN + row[q + 1]]));
                     w[q] = sv.x; w[q + 1] = sv.y;
                 }
@@ -396,7 +415,7 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvGemmArgs &a, const 
             if (y2u) {
 #pragma unroll
                 for (int q = 0; q < 8; q += 2) {
-                    f32x2 sv = snake_beta2(mk2(v[q], v[q + 1]), mk2(Pm[2 * BN + row[q]], Pm[2 * BN + row[q + 1]]),
+                    f32x2 sv = snake_beta2_t<FAST>(mk2(v[q], v[q + 1]), mk2(Pm[2 * BN + row[q]], Pm[2 * BN + row[q + 1]]),
                                            mk2(Pm[3 * BN + row[q]], Pm[3 * BN + row[q + 1]]));
                     if (ok[q]) { yu[o[q]] = v[q]; y2u[o[q]] = sv.x; }
                     if (ok[q + 1]) { yu[o[q + 1]] = v[q + 1]; y2u[o[q + 1]] = sv.y; }
@@ -404,7 +423,7 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvGemmArgs &a, const 
             } else {
 #pragma unroll
                 for (int q = 0; q < 8; q += 2) {
-                    f32x2 sv = snake_beta2(mk2(v[q], v[q + 1]), mk2(Pm[2 * BN + row[q]], Pm[2 * BN + row[q + 1]]),
+                    f32x2 sv = snake_beta2_t<FAST>(mk2(v[q], v[q + 1]), mk2(Pm[2 * BN + row[q]], Pm[2 * BN + row[q + 1]]),
                                            mk2(Pm[3 * BN + row[q]], Pm[3 * BN + row[q + 1]]));
                     if (ok[q]) yu[o[q]] = sv.x;
                     if (ok[q + 1]) yu[o[q + 1]] = sv.y;
@@ -420,7 +439,7 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvGemmArgs &a, const 
 
 // Epilogue of one output tile of the fused residual unit: y = res + (acc2 + b2) [then SnakeBeta]; resv holds the
 // residual prefetched before the second product; parameters from the LDS table (rows rbase + ...).
-template <int BN>
+template <int BN, bool FAST = false>
 __device__ __forceinline__ void fused_epilogue_tile(const ConvGemmArgs &a, const f32x16 &acc2, const float *resv, const float *Pm,
                                                     int rbase, int m, float *yu, unsigned short *ybu = nullptr) {
 #pragma unroll
@@ -440,7 +459,7 @@ __device__ __forceinline__ void fused_epilogue_tile(const ConvGemmArgs &a, const
             if (a.psn_a) {
 #pragma unroll
                 for (int q = 0; q < 8; q += 2) {
-                    f32x2 sv = snake_beta2(mk2(v[q], v[q + 1]), mk2(Pm[4 * BN + n[q]], Pm[4 * BN + n[q + 1]]),
+                    f32x2 sv = snake_beta2_t<FAST>(mk2(v[q], v[q + 1]), mk2(Pm[4 * BN + n[q]], Pm[4 * BN + n[q + 1]]),
                                            mk2(Pm[5 * BN + n[q]], Pm[5 * BN + n[q + 1]]));
                     v[q] = sv.x; v[q + 1] = sv.y;
                 }
@@ -455,7 +474,7 @@ __device__ __forceinline__ void fused_epilogue_tile(const ConvGemmArgs &a, const
         if (a.psn_a) {
 #pragma unroll
             for (int q = 0; q < 8; q += 2) {
-                f32x2 sv = snake_beta2(mk2(v[q], v[q + 1]), mk2(Pm[4 * BN + n[q]], Pm[4 * BN + n[q + 1]]),
+                f32x2 sv = snake_beta2_t<FAST>(mk2(v[q], v[q + 1]), mk2(Pm[4 * BN + n[q]], Pm[4 * BN + n[q + 1]]),
                                        mk2(Pm[5 * BN + n[q]], Pm[5 * BN + n[q + 1]]));
                 v[q] = sv.x; v[q + 1] = sv.y;
             }

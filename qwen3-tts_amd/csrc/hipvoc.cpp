@@ -1168,8 +1168,9 @@ static std::unique_ptr<Plan> build_plan(Ctx *c, int G, int T, bool debug, char *
         const float *x = cur, *w = c->fin_w_raw, *bias = g.bias, *sa = act_in ? nullptr : c->fin_snake.ea, *sib = act_in ? nullptr : c->fin_snake.ib;
         int Cf = g.Cin, GG = G, LL = L, LLp = Lp;
         Ctx *cc = c;
-        b.add("final_conv7", sa ? "final_conv_kernel<7,true>" : "final_conv_kernel<7,false>", (double)G * L * g.Cin * g.ntaps, [=](hipStream_t s) {
-            return launch_final_conv(x, cc->cur_out, w, bias, sa, sib, Cf, 7, GG, LL, LLp, cc->cur_out_stride, s);
+        const bool hw_snake = c->bf16 && !c->split3;             // the bf16 mode evaluates every SnakeBeta in its hardware form (device_common.h)
+        b.add("final_conv7", sa ? (hw_snake ? "final_conv_kernel<7,true,true>" : "final_conv_kernel<7,true>") : "final_conv_kernel<7,false>", (double)G * L * g.Cin * g.ntaps, [=](hipStream_t s) {
+            return launch_final_conv(x, cc->cur_out, w, bias, sa, sib, Cf, 7, GG, LL, LLp, cc->cur_out_stride, s, hw_snake);
         });
         plan->steps.back().bytes = ((double)g.Cin + 1.0) * G * L * 4;
         b.mark(st++, nullptr, 1, L, 0);

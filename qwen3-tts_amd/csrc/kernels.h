@@ -172,7 +172,7 @@ const char *dwconv_ln_kernel_name(int C, int K);
 
 // Final stage: SnakeBeta -> causal conv C->1 (w[C][K], K == 7; other K: use conv_gemm) -> clamp; out[u*out_stride + t]
 hipError_t launch_final_conv(const float *x, float *out, const float *w, const float *bias, const float *sn_a,
-                             const float *sn_ib, int C, int K, int G, int L, int Lp, long out_stride, hipStream_t s);
+                             const float *sn_ib, int C, int K, int G, int L, int Lp, long out_stride, hipStream_t s, bool fast_snake = false);
 
 // f32 -> i16 PCM: (s*32767.0).clamp(-32768.0, 32767.0) as i16   (src/worker/mod.rs:521-524)
 hipError_t launch_pcm16(const float *x, int16_t *y, long n, hipStream_t s);

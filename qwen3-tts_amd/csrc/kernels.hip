@@ -1102,8 +1102,10 @@ hipError_t launch_dwconv_ln(const float *x, float *y, const float *dw_w, const f
 // sn_a == null: x is already activated (the last residual unit applied the final SnakeBeta in its epilogue, once per
 // element instead of 2.5 times here) and the kernel is a plain 7-tap filter over C rows.
 // -------------------------------------------------------------------------------------------------
-template <int K, bool SN>      // SN: x is the raw tensor and the kernel applies the SnakeBeta itself (a compile-time choice: as a run-time
+template <int K, bool SN, bool FAST = false>      // SN: x is the raw tensor and the kernel applies the SnakeBeta itself (a compile-time choice: as a run-time
                                 // branch in the channel loop it kept hipcc from issuing the next channels' loads ahead of the arithmetic)
+                                // FAST: ... in the bf16 mode's form (device_common.h: snake_beta2_hw), so that WHERE the final activation
+                                // is applied (HIPVOC_FIN_POST) changes no bit in that mode either
 __global__ __launch_bounds__(256) void final_conv_kernel(const float *x, float *out, const float *w /*[C][K]*/,
                                                           const float *bias, const float *sn_a, const float *sn_ib,
                                                           int C, int G, int L, int Lp, long out_stride,
@@ -1152,7 +1154,7 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const float *x, float *
                 const f32x2 sa = (f32x2)(sn_a[c]), sib = (f32x2)(sn_ib[c]);
 #pragma unroll
                 for (int i = 2; i < 12; i += 2) {         // (sv[0], sv[1] are never read: K - 1 <= 6)
-                    f32x2 s2 = snake_beta2(mk2(sv[i], sv[i + 1]), sa, sib);
+                    f32x2 s2 = snake_beta2_t<FAST>(mk2(sv[i], sv[i + 1]), sa, sib);
                     int pos = t - 8 + i;
                     sv[i] = (pos >= 0 && pos < L) ? s2.x : 0.0f;        // zero padding applies to the activation output
                     sv[i + 1] = (pos + 1 >= 0 && pos + 1 < L) ? s2.y : 0.0f;
@@ -1179,13 +1181,16 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const float *x, float *
 }
 
 hipError_t launch_final_conv(const float *x, float *out, const float *w, const float *bias, const float *sn_a,
-                             const float *sn_ib, int C, int K, int G, int L, int Lp, long out_stride, hipStream_t s) {
+                             const float *sn_ib, int C, int K, int G, int L, int Lp, long out_stride, hipStream_t s, bool fast_snake) {
     if (G <= 0 || L <= 0) return hipSuccess;
     if (K != 7 || (Lp & 3) || ((uintptr_t)x & 15)) return hipErrorInvalidValue;
     int vec = ((out_stride & 3) == 0 && ((uintptr_t)out & 15) == 0) ? 1 : 0;
     int nthr = (L + 3) / 4;
     if ((sn_a == nullptr) != (sn_ib == nullptr)) return hipErrorInvalidValue;
-    if (sn_a)
+    if (sn_a && fast_snake)
+        hipLaunchKernelGGL((final_conv_kernel<7, true, true>), dim3((nthr + 255) / 256, G), dim3(256), 0, s, x, out, w, bias, sn_a, sn_ib, C,
+                           G, L, Lp, out_stride, vec);
+    else if (sn_a)
         hipLaunchKernelGGL((final_conv_kernel<7, true>), dim3((nthr + 255) / 256, G), dim3(256), 0, s, x, out, w, bias, sn_a, sn_ib, C,
                            G, L, Lp, out_stride, vec);
     else

@@ -53,6 +53,7 @@ template <int TN, bool FUSE, bool XB, bool X3, int OI = 0, int NW = 8>      // O
 __device__ __forceinline__ void conv_gemm_bf16_body(const ConvGemmArgs &a, int HL, int XW, int tiles_per_unit, int n_tiles) {
     constexpr int BMB = 32 * NW, NTHB = 64 * NW;      // (shadow the 8-wave constants of this file)
     constexpr int BN = TN * 32;
+    constexpr bool FS = !X3;                           // the bf16 mode's hardware SnakeBeta (device_common.h: snake_beta2_hw); bf16x3 keeps the polynomial
     constexpr int WF = 4 * BN;                        // 16-byte elements per W tile [4 k-groups][BN rows]
     constexpr int WPT = (WF + NTHB - 1) / NTHB;       // per thread: 1 (TN <= 4) or 2 (TN = 6); 3 for TN = 6 in 4 waves
     static_assert(WPT <= 3, "W staging registers");
@@ -189,10 +190,10 @@ __device__ __forceinline__ void conv_gemm_bf16_body(const ConvGemmArgs &a, int H
             const float4 *sa = reinterpret_cast<const float4 *>(Sn + c0);
             const float4 *sb = reinterpret_cast<const float4 *>(Sn + CinP + c0);
             float4 a0 = sa[0], a1 = sa[1], b0 = sb[0], b1 = sb[1];
-            f32x2 p0 = snake_beta2(mk2(v[0], v[1]), mk2(a0.x, a0.y), mk2(b0.x, b0.y));
-            f32x2 p1 = snake_beta2(mk2(v[2], v[3]), mk2(a0.z, a0.w), mk2(b0.z, b0.w));
-            f32x2 p2 = snake_beta2(mk2(v[4], v[5]), mk2(a1.x, a1.y), mk2(b1.x, b1.y));
-            f32x2 p3 = snake_beta2(mk2(v[6], v[7]), mk2(a1.z, a1.w), mk2(b1.z, b1.w));
+            f32x2 p0 = snake_beta2_t<FS>(mk2(v[0], v[1]), mk2(a0.x, a0.y), mk2(b0.x, b0.y));
+            f32x2 p1 = snake_beta2_t<FS>(mk2(v[2], v[3]), mk2(a0.z, a0.w), mk2(b0.z, b0.w));
+            f32x2 p2 = snake_beta2_t<FS>(mk2(v[4], v[5]), mk2(a1.x, a1.y), mk2(b1.x, b1.y));
+            f32x2 p3 = snake_beta2_t<FS>(mk2(v[6], v[7]), mk2(a1.z, a1.w), mk2(b1.z, b1.w));
             v[0] = p0.x; v[1] = p0.y; v[2] = p1.x; v[3] = p1.y; v[4] = p2.x; v[5] = p2.y; v[6] = p3.x; v[7] = p3.y;
         }
         const bf16x8 hi = pack8(v);
@@ -321,7 +322,7 @@ __device__ __forceinline__ void conv_gemm_bf16_body(const ConvGemmArgs &a, int H
             for (int r = 0; r < 16; r++) {
                 int n = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (r & 1) {   // registers r-1, r are channels n-1, n: one packed evaluation for the pair
-                    f32x2 hv = snake_beta2(mk2(acc[i][r - 1] + Pm[n - 1], acc[i][r] + Pm[n]), mk2(Pm[BN + n - 1], Pm[BN + n]),
+                    f32x2 hv = snake_beta2_t<FS>(mk2(acc[i][r - 1] + Pm[n - 1], acc[i][r] + Pm[n]), mk2(Pm[BN + n - 1], Pm[BN + n]),
                                            mk2(Pm[2 * BN + n - 1], Pm[2 * BN + n]));
                     acc[i][r - 1] = hv.x;
                     acc[i][r] = hv.y;
@@ -402,7 +403,7 @@ __device__ __forceinline__ void conv_gemm_bf16_body(const ConvGemmArgs &a, int H
                 }
             }
             dep2 = acc2[15];
-            fused_epilogue_tile<BN>(a, acc2, resv, Pm, o * 32 + 4 * h, m, yu, ybu);
+            fused_epilogue_tile<BN, FS>(a, acc2, resv, Pm, o * 32 + 4 * h, m, yu, ybu);
         }
         return;
     }
@@ -417,11 +418,11 @@ __device__ __forceinline__ void conv_gemm_bf16_body(const ConvGemmArgs &a, int H
     unsigned short *ybu0 = launder_after(a.yb, acc[TN - 1][15]);
     unsigned short *ybu = ybu0 ? ybu0 + (((long)unit * a.y_us) << 3) : nullptr;
     if constexpr (OI == 3) {
-        tconv_pt_epilogue<BN, TN>(a, acc, Pm, n0, h, m, yu, y2u, ybu);
+        tconv_pt_epilogue<BN, TN, FS>(a, acc, Pm, n0, h, m, yu, y2u, ybu);
         return;
     }
 #pragma unroll
-    for (int i = 0; i < TN; i++) conv_epilogue_tile<BN, false, OI == 2>(a, acc[i], Pm, n0, i * 32 + 4 * h, m, yu, ru, y2u, ybu);
+    for (int i = 0; i < TN; i++) conv_epilogue_tile<BN, false, OI == 2, FS>(a, acc[i], Pm, n0, i * 32 + 4 * h, m, yu, ru, y2u, ybu);
 }
 
 template <int TN, bool FUSE, bool XB>

@@ -32,7 +32,7 @@ typedef const __attribute__((address_space(3))) rg_bf16x8 *rg_lds16_t;
 
 #ifndef RG_ABL
 #define RG_ABL 0          // timing-only experiments (results are wrong with any bit set): 1 = no weight DMA after the prologue,
-#endif                    // 2 = no activation DMA after the prologue, 4 = no barriers, 16 = no LDS operand reads
+#endif                    // 2 = no activation DMA after the prologue, 4 = no barriers, 8 = one store per lane instead of the epilogue, 16 = no LDS operand reads
 
 namespace ring {
 constexpr int NW = 4, NTH = 64 * NW;        // waves per workgroup, threads
@@ -228,6 +228,18 @@ __global__ __launch_bounds__(ring::NTH, 2) void conv7_bf16_ring_kernel(ConvGemmA
     }
 
     // epilogue (conv_gemm_bf16_kernel's): bias, residual, optional SnakeBeta, fp32 and / or packed stores
+    if ((RG_ABL & 8) && a.yb) {                     // timing only: one 8-byte store per lane instead
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < TN; i++)
+#pragma unroll
+            for (int p = 0; p < PT; p++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) t += acc[i][p][r];
+        const int m = m0 + wave * 64 + l31;
+        if (m < a.M) *reinterpret_cast<uint2 *>(a.yb + ((((long)((n0 + 4 * h) >> 3) * a.y_cs + (long)unit * a.y_us + m) << 3) + ((n0 + 4 * h) & 4))) = pack4_bf16(t, t, t, t);
+        return;
+    }
     float *yu = a.y ? a.y + (long)unit * a.y_us : nullptr;
     const float *ru0 = launder_after(a.res, acc[TN - 1][PT - 1][15]);
     const float *ru = ru0 ? ru0 + (long)unit * a.y_us : nullptr;
@@ -239,8 +251,8 @@ __global__ __launch_bounds__(ring::NTH, 2) void conv7_bf16_ring_kernel(ConvGemmA
     static_assert(PT == 2 && TN <= 6, "the epilogue below is written out for these");
 #define RG_EPI(i_)                                                                                                                    \
     if constexpr ((i_) < TN) {                                                                                                       \
-        conv_epilogue_tile<BN, false, false>(a, acc[(i_) < TN ? (i_) : 0][0], Pm, n0, (i_)*32 + 4 * h, m0 + wave * 64 + l31, yu, ru, y2u, ybu);      \
-        conv_epilogue_tile<BN, false, false>(a, acc[(i_) < TN ? (i_) : 0][1], Pm, n0, (i_)*32 + 4 * h, m0 + wave * 64 + 32 + l31, yu, ru, y2u, ybu); \
+        conv_epilogue_tile<BN, false, false, true>(a, acc[(i_) < TN ? (i_) : 0][0], Pm, n0, (i_)*32 + 4 * h, m0 + wave * 64 + l31, yu, ru, y2u, ybu);      \
+        conv_epilogue_tile<BN, false, false, true>(a, acc[(i_) < TN ? (i_) : 0][1], Pm, n0, (i_)*32 + 4 * h, m0 + wave * 64 + 32 + l31, yu, ru, y2u, ybu); \
     }
     RG_EPI(0) RG_EPI(1) RG_EPI(2) RG_EPI(3) RG_EPI(4) RG_EPI(5)
 #undef RG_EPI
@@ -450,14 +462,14 @@ __global__ __launch_bounds__(ring::NTH, 2) void conv_bf16_ring_kernel(ConvGemmAr
     unsigned short *ybu = ybu0 ? ybu0 + (((long)unit * a.y_us) << 3) : nullptr;
     static_assert(PT == 2 && TN <= 6, "the epilogue below is written out for these");
     if constexpr (EPI == 3) {
-        tconv_pt_epilogue<BN, TN>(a, acc[0], Pm, n0, h, m0 + wave * 64 + l31, yu, y2u, ybu);
-        tconv_pt_epilogue<BN, TN>(a, acc[1], Pm, n0, h, m0 + wave * 64 + 32 + l31, yu, y2u, ybu);
+        tconv_pt_epilogue<BN, TN, true>(a, acc[0], Pm, n0, h, m0 + wave * 64 + l31, yu, y2u, ybu);
+        tconv_pt_epilogue<BN, TN, true>(a, acc[1], Pm, n0, h, m0 + wave * 64 + 32 + l31, yu, y2u, ybu);
     } else {
         // (written out: left as loops, hipcc keeps them rolled -- the body is large -- and the accumulators move to scratch)
 #define RG_EPI(i_)                                                                                                                    \
     if constexpr ((i_) < TN) {                                                                                                       \
-        conv_epilogue_tile<BN, false, EPI == 2>(a, acc[0][(i_) < TN ? (i_) : 0], Pm, n0, (i_)*32 + 4 * h, m0 + wave * 64 + l31, yu, ru, y2u, ybu);      \
-        conv_epilogue_tile<BN, false, EPI == 2>(a, acc[1][(i_) < TN ? (i_) : 0], Pm, n0, (i_)*32 + 4 * h, m0 + wave * 64 + 32 + l31, yu, ru, y2u, ybu); \
+        conv_epilogue_tile<BN, false, EPI == 2, true>(a, acc[0][(i_) < TN ? (i_) : 0], Pm, n0, (i_)*32 + 4 * h, m0 + wave * 64 + l31, yu, ru, y2u, ybu);      \
+        conv_epilogue_tile<BN, false, EPI == 2, true>(a, acc[1][(i_) < TN ? (i_) : 0], Pm, n0, (i_)*32 + 4 * h, m0 + wave * 64 + 32 + l31, yu, ru, y2u, ybu); \
     }
         RG_EPI(0) RG_EPI(1) RG_EPI(2) RG_EPI(3) RG_EPI(4) RG_EPI(5)
 #undef RG_EPI
@@ -641,7 +653,7 @@ __global__ __launch_bounds__(ringu::NTH, 2) void resunit_bf16_ring_kernel(ConvGe
         for (int r = 0; r < 16; r++) {
             const int n = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (r & 1) {
-                f32x2 hv = snake_beta2(mk2(acc[i][r - 1] + Pm[n - 1], acc[i][r] + Pm[n]), mk2(Pm[BN + n - 1], Pm[BN + n]),
+                f32x2 hv = snake_beta2_t<true>(mk2(acc[i][r - 1] + Pm[n - 1], acc[i][r] + Pm[n]), mk2(Pm[BN + n - 1], Pm[BN + n]),
                                        mk2(Pm[2 * BN + n - 1], Pm[2 * BN + n]));
                 acc[i][r - 1] = hv.x;
                 acc[i][r] = hv.y;
@@ -682,7 +694,7 @@ __global__ __launch_bounds__(ringu::NTH, 2) void resunit_bf16_ring_kernel(ConvGe
 #pragma unroll
             for (int g = 0; g < 2; g++) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2q[o & 1][i * 2 + g], hb[i][g], acc2, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        fused_epilogue_tile<BN>(a, acc2, resv[o & 1], Pm, o * 32 + 4 * h, m, yu, ybu);
+        fused_epilogue_tile<BN, true>(a, acc2, resv[o & 1], Pm, o * 32 + 4 * h, m, yu, ybu);
     }
 }
 
@@ -878,7 +890,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 1 : 2)) void conv7_bf16_ring8_k
     // (written out: left as loops, hipcc keeps them rolled -- the body is large -- and the accumulators move to scratch)
 #define RG_EPI1(i_, p_)                                                                                                              \
     if constexpr ((i_) < TN && (p_) < PT)                                                                                            \
-        conv_epilogue_tile<BN, false, false>(a, acc[(i_) < TN ? (i_) : 0][(p_) < PT ? (p_) : 0], Pm, n0, (i_)*32 + 4 * h,            \
+        conv_epilogue_tile<BN, false, false, true>(a, acc[(i_) < TN ? (i_) : 0][(p_) < PT ? (p_) : 0], Pm, n0, (i_)*32 + 4 * h,            \
                                              m0 + wave * (32 * PT) + (p_)*32 + l31, yu, ru, y2u, ybu);
 #define RG_EPI(i_) RG_EPI1(i_, 0) RG_EPI1(i_, 1) RG_EPI1(i_, 2) RG_EPI1(i_, 3)
     RG_EPI(0) RG_EPI(1) RG_EPI(2) RG_EPI(3) RG_EPI(4) RG_EPI(5)

@@ -98,7 +98,7 @@ __device__ __forceinline__ f32x2 b3_snake2(f32x2 x, f32x2 ea, f32x2 ib) {
     const float s0 = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(rev.x)), s1 = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(rev.y));
     return fma2(ib, mk2(s0 * s0, s1 * s1), x);
 #else
-    return snake_beta2(x, ea, ib);
+    return snake_beta2_t<true>(x, ea, ib);      // (the bf16 mode's form: device_common.h)
 #endif
 }
 

@@ -631,7 +631,7 @@ __device__ __forceinline__ void gemm1_bf16_body(const ConvGemmArgs &a, int tiles
     float *y2u = y2u0 ? y2u0 + (long)unit * a.y_us : nullptr;
     const int m = m0 + wave * 32 + l31;
 #pragma unroll
-    for (int i = 0; i < TN; i++) conv_epilogue_tile<BN>(a, acc[i], Pm, n0, i * 32 + 4 * h, m, yu, ru, y2u);
+    for (int i = 0; i < TN; i++) conv_epilogue_tile<BN, false, false, !X3>(a, acc[i], Pm, n0, i * 32 + 4 * h, m, yu, ru, y2u);
 }
 
 template <int TN>
@@ -831,10 +831,10 @@ __device__ __forceinline__ void convs_bf16_body(const ConvGemmArgs &a, int HL, i
                     const float4 *sa = reinterpret_cast<const float4 *>(Sn + (c0 < ngr * 8 ? c0 : 0));
                     const float4 *sb = reinterpret_cast<const float4 *>(Sn + ngr * 8 + (c0 < ngr * 8 ? c0 : 0));
                     const float4 a0 = sa[0], a1 = sa[1], b0 = sb[0], b1 = sb[1];
-                    const f32x2 p0 = snake_beta2(mk2(f[0], f[1]), mk2(a0.x, a0.y), mk2(b0.x, b0.y));
-                    const f32x2 p1 = snake_beta2(mk2(f[2], f[3]), mk2(a0.z, a0.w), mk2(b0.z, b0.w));
-                    const f32x2 p2 = snake_beta2(mk2(f[4], f[5]), mk2(a1.x, a1.y), mk2(b1.x, b1.y));
-                    const f32x2 p3 = snake_beta2(mk2(f[6], f[7]), mk2(a1.z, a1.w), mk2(b1.z, b1.w));
+                    const f32x2 p0 = snake_beta2_t<!X3>(mk2(f[0], f[1]), mk2(a0.x, a0.y), mk2(b0.x, b0.y));
+                    const f32x2 p1 = snake_beta2_t<!X3>(mk2(f[2], f[3]), mk2(a0.z, a0.w), mk2(b0.z, b0.w));
+                    const f32x2 p2 = snake_beta2_t<!X3>(mk2(f[4], f[5]), mk2(a1.x, a1.y), mk2(b1.x, b1.y));
+                    const f32x2 p3 = snake_beta2_t<!X3>(mk2(f[6], f[7]), mk2(a1.z, a1.w), mk2(b1.z, b1.w));
                     f[0] = p0.x; f[1] = p0.y; f[2] = p1.x; f[3] = p1.y; f[4] = p2.x; f[5] = p2.y; f[6] = p3.x; f[7] = p3.y;
                 }
 #pragma unroll
@@ -898,7 +898,7 @@ __device__ __forceinline__ void convs_bf16_body(const ConvGemmArgs &a, int HL, i
     unsigned short *ybu0 = launder_after(a.yb, acc[15]);
     unsigned short *ybu = ybu0 ? ybu0 + (((long)unit * a.y_us) << 3) : nullptr;
     const int m = m0 + wave * 32 + l31;
-    conv_epilogue_tile<BN>(a, acc, Pm, n0, 4 * h, m, yu, ru, y2u, ybu);
+    conv_epilogue_tile<BN, false, false, !X3>(a, acc, Pm, n0, 4 * h, m, yu, ru, y2u, ybu);
 }
 
 template <bool XB>
