@@ -130,6 +130,11 @@ int hipvoc_vocode_pcm16_batch(void *h, const uint8_t *codes_le, const int32_t *n
  * d_out [n_units, unit_stride] f32 are DEVICE pointers (unit_stride >= hipvoc_unit_samples, in
  * floats).  Work is enqueued on the handle's stream; call hipvoc_sync to wait and collect
  * deferred errors (out-of-range codes are detected on the device).
+ * A call of more than hipvoc_group units runs as several passes.  In the bf16 mode (env HIPVOC_LANES, default 2 there,
+ * 1 in fp32 / bf16x3) those passes alternate between the handle's stream and a second stream of the handle with a
+ * workspace of its own, so that one pass's tail overlaps the next one's head; the second stream starts behind everything
+ * already enqueued on the handle's stream and the handle's stream ends behind it, so the ordering contract above
+ * (hipvoc_sync, or events on hipvoc_stream) is unchanged, and the samples are those of one lane bit for bit.
  */
 int hipvoc_decode_units_device(void *h, const int64_t *d_codes, int n_units, float *d_out, size_t unit_stride);
 int hipvoc_sync(void *h);

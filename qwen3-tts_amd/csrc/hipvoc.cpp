@@ -140,6 +140,12 @@ struct Ctx {
     int dual_out = 1;          // un-fused residual units, SnakeBeta in the producer's epilogue: 0 never, 1 conv7 -> conv1 only
                                // (no extra write), 2 also x / snake(x) written side by side (HIPVOC_DUAL)
     hipStream_t stream = nullptr;
+    // Two LANES (bf16 mode by default; HIPVOC_LANES): hipvoc_decode_units_device alternates the passes of one call between two
+    // streams with a workspace each, so that the HBM-bound launches of one pass run under the MFMA-bound ones of the other and
+    // the tails of both fill; ordered against the handle's stream by events on both sides (include/hipvoc.h's contract holds)
+    int lanes = 1, buf_lane = 0;
+    hipStream_t stream2 = nullptr;
+    hipEvent_t lane_ev[2] = {nullptr, nullptr};
     std::string err;
     std::vector<void *> dev_allocs;
 
@@ -170,6 +176,7 @@ struct Ctx {
     std::map<int, std::pair<float *, size_t>> bufs;
     bool ws_frozen = false;
     std::map<std::pair<int, int>, std::unique_ptr<Plan>> plans;
+    std::map<std::pair<int, int>, std::unique_ptr<Plan>> plans_lane1;
     // hipvoc_decode_units_device_noalloc: this device's copy of the static scratch array (scratch.hip) and the plans
     // whose workspace is carved out of it
     void *scratch = nullptr;
@@ -218,6 +225,8 @@ struct Ctx {
             if (ev_done[s]) (void)hipEventDestroy(ev_done[s]);
             if (ev_copied[s]) (void)hipEventDestroy(ev_copied[s]);
         }
+        for (int l = 0; l < 2; l++) if (lane_ev[l]) (void)hipEventDestroy(lane_ev[l]);
+        if (stream2) (void)hipStreamDestroy(stream2);
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -756,6 +765,7 @@ struct PlanBuilder {
             sbufs[id] = {ptr, floats};
             return ptr;
         }
+        id += 1000 * c->buf_lane;      // (the second lane's workspace: its own set of buffers)
         auto it = c->bufs.find(id);
         if (it != c->bufs.end() && it->second.second >= floats) return it->second.first;
         if (c->ws_frozen) {
@@ -1195,9 +1205,14 @@ static std::unique_ptr<Plan> build_plan(Ctx *c, int G, int T, bool debug, char *
     return plan;
 }
 
-static Plan *get_plan(Ctx *c, int G, int T, bool debug = false, bool in_scratch = false) {
+static Plan *get_plan(Ctx *c, int G, int T, bool debug = false, bool in_scratch = false, int lane = 0) {
     auto key = std::make_pair(debug ? -G : G, T);
-    auto &cache = in_scratch ? c->scratch_plans : c->plans;
+    auto &cache = in_scratch ? c->scratch_plans : (lane ? c->plans_lane1 : c->plans);
+    struct LaneScope {                 // build_plan takes the lane's buffers (PlanBuilder::buf)
+        Ctx *c; int prev;
+        LaneScope(Ctx *c_, int lane_) : c(c_), prev(c_->buf_lane) { c->buf_lane = lane_; }
+        ~LaneScope() { c->buf_lane = prev; }
+    } lane_scope(c, in_scratch ? 0 : lane);
     auto it = cache.find(key);
     if (it != cache.end()) return it->second.get();
     std::unique_ptr<Plan> plan;
@@ -1256,7 +1271,8 @@ struct RoctxRange {
 
 // Runs the plan for one group.  stop_stage >= 0: stop after the step that completes it.
 static int run_plan(Ctx *c, Plan *p, const long long *d_codes, float *d_out, long out_stride, int stop_stage,
-                    const Step **stopped) {
+                    const Step **stopped, hipStream_t on = nullptr) {
+    const hipStream_t stream = on ? on : c->stream;
     c->cur_codes = d_codes;
     c->cur_out = d_out;
     c->cur_out_stride = out_stride;
@@ -1264,7 +1280,7 @@ static int run_plan(Ctx *c, Plan *p, const long long *d_codes, float *d_out, lon
     if (c->profile) {
         ev.resize(p->steps.size() + 1);
         for (auto &e : ev) HIPCHK(hipEventCreate(&e));
-        HIPCHK(hipEventRecord(ev[0], c->stream));
+        HIPCHK(hipEventRecord(ev[0], stream));
     }
     // HIPVOC_TRACE_STEPS=1: the launch sequence of every pass on stderr, for tools that attribute per-dispatch profiler
     // rows (rocprofv3 counter CSVs are in dispatch order) to steps: "HIPVOC_STEP <index> <step> <kernel> <macs> <bytes>"
@@ -1279,12 +1295,12 @@ static int run_plan(Ctx *c, Plan *p, const long long *d_codes, float *d_out, lon
         char rname[160];
         if (roctx().push) snprintf(rname, sizeof rname, "%s|%s", s.name, s.kernel);
         RoctxRange step_range(roctx().push ? rname : "");
-        hipError_t e = s.run(c->stream);
+        hipError_t e = s.run(stream);
         if (e != hipSuccess) {
             c->err = fmt("launch of %s failed: %s", s.name, hipGetErrorString(e));
             return HIPVOC_E_HIP;
         }
-        if (c->profile) HIPCHK(hipEventRecord(ev[i + 1], c->stream));
+        if (c->profile) HIPCHK(hipEventRecord(ev[i + 1], stream));
         ran = i + 1;
         if (stop_stage >= 0 && s.stage == stop_stage) {
             if (stopped) *stopped = &s;
@@ -1292,7 +1308,7 @@ static int run_plan(Ctx *c, Plan *p, const long long *d_codes, float *d_out, lon
         }
     }
     if (c->profile) {
-        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipStreamSynchronize(stream));
         c->prof_names.clear(); c->prof_ms.clear(); c->prof_flops.clear(); c->prof_launches.clear();
         for (size_t i = 0; i < ran; i++) {
             float ms = 0;
@@ -1318,12 +1334,24 @@ static int run_plan(Ctx *c, Plan *p, const long long *d_codes, float *d_out, lon
 
 static int decode_units_device(Ctx *c, const long long *d_codes, int n_units, float *d_out, size_t unit_stride) {
     int T = c->unit_frames;
-    for (int u0 = 0; u0 < n_units; u0 += c->group) {
+    const bool two = c->lanes == 2 && c->stream2 && !c->profile && n_units > c->group;
+    if (two) {                                                  // the second lane starts behind whatever the handle's stream holds
+        HIPCHK(hipEventRecord(c->lane_ev[0], c->stream));
+        HIPCHK(hipStreamWaitEvent(c->stream2, c->lane_ev[0], 0));
+    }
+    int k = 0;
+    for (int u0 = 0; u0 < n_units; u0 += c->group, k++) {
         int G = std::min(c->group, n_units - u0);
-        Plan *p = get_plan(c, G, T);
+        const int lane = two ? (k & 1) : 0;
+        Plan *p = get_plan(c, G, T, false, false, lane);
         if (!p) return HIPVOC_E_HIP;
-        int rc = run_plan(c, p, d_codes + (size_t)u0 * T * c->n_q, d_out + (size_t)u0 * unit_stride, (long)unit_stride, -1, nullptr);
+        int rc = run_plan(c, p, d_codes + (size_t)u0 * T * c->n_q, d_out + (size_t)u0 * unit_stride, (long)unit_stride, -1, nullptr,
+                          lane ? c->stream2 : c->stream);
         if (rc) return rc;
+    }
+    if (two) {                                                  // ... and the handle's stream ends behind both lanes
+        HIPCHK(hipEventRecord(c->lane_ev[1], c->stream2));
+        HIPCHK(hipStreamWaitEvent(c->stream, c->lane_ev[1], 0));
     }
     return HIPVOC_OK;
 }
@@ -1570,6 +1598,19 @@ static void *load_impl(const char *weights_path, int device_id, int dtype, int u
     // size the workspace for a full group now, so later calls never allocate inside the plan
     Plan *p = get_plan(c.get(), c->group, unit_frames);
     if (!p) return fail(c->err.empty() ? "workspace allocation failed" : c->err);
+    {
+        // bf16 mode: two lanes by default (measured on MI355X, 512 units per call: 237.5 -> 229.6 ms; fp32: 957.5 -> 961.8, so one)
+        int lanes = (c->bf16 && !c->split3) ? 2 : 1;
+        if (const char *ls = getenv("HIPVOC_LANES")) lanes = atoi(ls) == 2 ? 2 : 1;
+        if (lanes == 2) {
+            if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&c->lane_ev[0], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&c->lane_ev[1], hipEventDisableTiming) != hipSuccess)
+                return fail("lane stream / event creation failed");
+            if (!get_plan(c.get(), c->group, unit_frames, false, false, 1)) return fail(c->err.empty() ? "workspace allocation failed (second lane)" : c->err);
+            c->lanes = 2;
+        }
+    }
     c->ws_frozen = true;
     double macs = 0;
     for (auto &s : p->steps) macs += s.macs;

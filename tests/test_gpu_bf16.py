@@ -358,3 +358,34 @@ def test_bf16_resunit_ring_kernel_bitwise(pkg, synth, unit, frames, n_seq, monke
         for a, b in zip(outs[0], other):
             assert a.size == b.size and a.size > 0
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), float(np.abs(a - b).max())
+
+
+@pytest.mark.parametrize("dtype,n_units", [(BF16, 200), (0, 150)])
+def test_two_lanes_of_one_handle_bitwise_and_ordered(pkg, synth, dtype, n_units, monkeypatch):
+    """hipvoc_decode_units_device with HIPVOC_LANES=2 (the bf16 mode's default) alternates the passes of one call between two streams
+    with a workspace each.  Same kernels on the same inputs: the waveforms are those of one lane, bit for bit -- for a call of several
+    passes with a ragged last one, for two calls back to back without a sync in between (the second call's lanes start behind the
+    first call's), and the handle's own stream ends behind both lanes (hipvoc_sync alone makes every output readable)."""
+    import torch
+    cfg = synth.FULL
+    path = os.path.join(tempfile.gettempdir(), "hipvoc_test_FULL_0.safetensors")
+    if not os.path.exists(path):
+        synth.save_safetensors(path, weights_for(synth, "FULL", 0), cfg.metadata())
+    T = 8
+    codes = np.stack([synth.make_codes(T, 5000 + i, cfg) for i in range(n_units)])
+    d_codes = torch.from_numpy(codes).cuda()
+    outs = []
+    for lanes in ("1", "2"):
+        monkeypatch.setenv("HIPVOC_LANES", lanes)                  # read at load
+        v = pkg.HipVocoder.load(path, device=0, unit_frames=T, dtype=dtype)
+        stride = (v.unit_samples + 63) // 64 * 64
+        d_out = torch.zeros((2, n_units, stride), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        v.decode_units_device(d_codes.data_ptr(), n_units, d_out[0].data_ptr(), stride)
+        v.decode_units_device(d_codes.data_ptr(), n_units - 70, d_out[1].data_ptr(), stride)       # no sync in between
+        v.sync()
+        outs.append(d_out.cpu().numpy()[:, :, : v.unit_samples].copy())
+        v.close()
+    assert np.abs(outs[0][0]).max() > 0
+    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+    assert np.array_equal(outs[1][0, : n_units - 70].view(np.uint32), outs[1][1, : n_units - 70].view(np.uint32))
