@@ -1460,6 +1460,12 @@ static int decode_host(Ctx *c, const void *codes, const int32_t *n_frames, int B
         }
         return HIPVOC_OK;
     };
+    // two lanes (bf16 mode): pass k computes on lane k & 1 -- its slot, its workspace, its stream -- beside pass k - 1
+    const bool two = c->lanes == 2 && c->stream2 && !c->profile && total_units > (size_t)c->group;
+    if (two) {
+        HIPCHK(hipEventRecord(c->lane_ev[0], c->stream));
+        HIPCHK(hipStreamWaitEvent(c->stream2, c->lane_ev[0], 0));
+    }
     UnitWalker walk(n_frames, B, T, Lu, out_off);
     int cur_seq = 0, pending = -1;
     size_t seq_frame0 = 0;                 // first frame of sequence cur_seq in `codes`
@@ -1481,19 +1487,20 @@ static int decode_host(Ctx *c, const void *codes, const int32_t *n_frames, int B
             memcpy(c->h_codes[s] + (size_t)i * unit_codes, cbytes + (seq_frame0 + (size_t)us[i].start) * nq * sizeof(int64_t),
                    (size_t)us[i].len * nq * sizeof(int64_t));
         }
-        HIPCHK(hipMemcpyAsync(c->d_codes_slot[s], c->h_codes[s], (size_t)G * unit_codes * sizeof(long long), hipMemcpyHostToDevice, c->stream));
-        Plan *p = get_plan(c, G, T);
+        hipStream_t on = (two && s) ? c->stream2 : c->stream;
+        HIPCHK(hipMemcpyAsync(c->d_codes_slot[s], c->h_codes[s], (size_t)G * unit_codes * sizeof(long long), hipMemcpyHostToDevice, on));
+        Plan *p = get_plan(c, G, T, false, false, two ? s : 0);
         if (!p) return HIPVOC_E_HIP;
-        int rc = run_plan(c, p, c->d_codes_slot[s], c->d_wave_slot[s], (long)stride, -1, nullptr);
+        int rc = run_plan(c, p, c->d_codes_slot[s], c->d_wave_slot[s], (long)stride, -1, nullptr, on);
         if (rc) return rc;
         const size_t n_el = (size_t)(G - 1) * stride + us.back().keep;              // one contiguous copy per pass
         const void *d_src = c->d_wave_slot[s];
         if (pcm) {
-            hipError_t e = launch_pcm16(c->d_wave_slot[s], c->d_pcm_slot[s], (long)n_el, c->stream);
+            hipError_t e = launch_pcm16(c->d_wave_slot[s], c->d_pcm_slot[s], (long)n_el, on);
             if (e != hipSuccess) { c->err = std::string("pcm16 launch: ") + hipGetErrorString(e); return HIPVOC_E_HIP; }
             d_src = c->d_pcm_slot[s];
         }
-        HIPCHK(hipEventRecord(c->ev_done[s], c->stream));
+        HIPCHK(hipEventRecord(c->ev_done[s], on));
         HIPCHK(hipStreamWaitEvent(c->copy_stream, c->ev_done[s], 0));
         HIPCHK(hipMemcpyAsync(c->h_out[s], d_src, n_el * esz, hipMemcpyDeviceToHost, c->copy_stream));
         HIPCHK(hipEventRecord(c->ev_copied[s], c->copy_stream));
@@ -1507,6 +1514,10 @@ static int decode_host(Ctx *c, const void *codes, const int32_t *n_frames, int B
         int rc = drain(pending);
         if (rc) return rc;
     }
+    if (two) {                                                  // the handle's stream ends behind the second lane
+        HIPCHK(hipEventRecord(c->lane_ev[1], c->stream2));
+        HIPCHK(hipStreamWaitEvent(c->stream, c->lane_ev[1], 0));
+    }
     return sync_check(c);
 }
 
@@ -1516,6 +1527,7 @@ static int decode_host_safe(Ctx *c, const void *codes, const int32_t *n_frames, 
     int rc = decode_host(c, codes, n_frames, B, out, pcm, out_off, out_cap, n_out, whole_unit);
     if (rc) {
         (void)hipStreamSynchronize(c->stream);
+        if (c->stream2) (void)hipStreamSynchronize(c->stream2);
         (void)hipStreamSynchronize(c->copy_stream);
     }
     return rc;

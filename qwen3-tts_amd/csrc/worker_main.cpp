@@ -463,6 +463,9 @@ int main(int argc, char **argv) {
     // MI355X over TCP (tools/worker_load.py): fp32 1754 -> 1788 audio-s/s, bf16 6417 -> 8031, i.e. 93-94 % of the
     // device-resident bench line.  (A device may also be listed more than once.)
     if (contexts < 1) contexts = 1;
+    // two contexts on a device already are two passes side by side: the handles' own second lane (hipvoc.h, HIPVOC_LANES) would
+    // only add a workspace each, so it stays off here unless the operator asks for it
+    if (contexts > 1) setenv("HIPVOC_LANES", "1", 0);
     for (size_t p = 0; p <= devices.size();) {
         size_t e = devices.find(',', p);
         if (e == std::string::npos) e = devices.size();

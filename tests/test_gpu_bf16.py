@@ -374,7 +374,8 @@ def test_two_lanes_of_one_handle_bitwise_and_ordered(pkg, synth, dtype, n_units,
     T = 8
     codes = np.stack([synth.make_codes(T, 5000 + i, cfg) for i in range(n_units)])
     d_codes = torch.from_numpy(codes).cuda()
-    outs = []
+    seqs = [synth.make_codes(n, 6000 + i, cfg) for i, n in enumerate([3, 21, 8, 1, 40, 17] * 25)]          # 350 units of 8 frames
+    outs, host, pcm = [], [], []
     for lanes in ("1", "2"):
         monkeypatch.setenv("HIPVOC_LANES", lanes)                  # read at load
         v = pkg.HipVocoder.load(path, device=0, unit_frames=T, dtype=dtype)
@@ -385,7 +386,12 @@ def test_two_lanes_of_one_handle_bitwise_and_ordered(pkg, synth, dtype, n_units,
         v.decode_units_device(d_codes.data_ptr(), n_units - 70, d_out[1].data_ptr(), stride)       # no sync in between
         v.sync()
         outs.append(d_out.cpu().numpy()[:, :, : v.unit_samples].copy())
+        # the host entry points take the same lanes (pass k in slot k & 1 on lane k & 1): ragged sequences over several passes
+        host.append(np.concatenate(v.synthesize_batch(seqs)))
+        pcm.append(b"".join(b for b, _ in v.handle_vocode_batch([q.astype("<i8").tobytes() for q in seqs], [len(q) for q in seqs])))
         v.close()
     assert np.abs(outs[0][0]).max() > 0
     assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+    assert host[0].size > 1800 * sum(len(q) for q in seqs) and np.array_equal(host[0].view(np.uint32), host[1].view(np.uint32))
+    assert len(pcm[0]) == 2 * host[0].size and pcm[0] == pcm[1]
     assert np.array_equal(outs[1][0, : n_units - 70].view(np.uint32), outs[1][1, : n_units - 70].view(np.uint32))
