@@ -180,6 +180,17 @@ __device__ __forceinline__ uint2 pack4_bf16(float a, float b, float c, float d) 
     return make_uint2((unsigned)bf16_bits(a) | ((unsigned)bf16_bits(b) << 16), (unsigned)bf16_bits(c) | ((unsigned)bf16_bits(d) << 16));
 }
 
+__device__ __forceinline__ float bf16_round(float f) { return (float)(__bf16)f; }
+__device__ __forceinline__ void unpack4_bf16(uint2 u, float *o) {
+    o[0] = __uint_as_float(u.x << 16); o[1] = __uint_as_float(u.x & 0xffff0000u);
+    o[2] = __uint_as_float(u.y << 16); o[3] = __uint_as_float(u.y & 0xffff0000u);
+}
+// ConvGemmArgs::rbf == 2: the packed bf16 tensor behind a float-typed field, at the unit the kernel's fp32 pointer arithmetic chose
+// (pu = field + unit * y_us in floats; the packed tensor counts the same strides in 16-byte elements)
+__device__ __forceinline__ unsigned short *rbf_packed(const float *field, const float *pu) {
+    return reinterpret_cast<unsigned short *>(const_cast<float *>(field)) + ((pu - field) << 3);
+}
+
 // ybu != null (bf16 packed output, see ConvGemmArgs::yb): yu (may be null) gets the raw value, ybu the activated one
 // as bf16 in channel-group-major form.  For S == 1 a lane's four rows (r&3) are half of a channel group: one 8-byte
 // store; the same holds for transposed convs with phase-major rows (ConvGemmArgs::pm); with channel-major rows
@@ -209,8 +220,19 @@ __device__ __forceinline__ void tconv_oi_epilogue_tile(const ConvGemmArgs &a, co
         }
     }
     const long pos = (long)m * S + ph0;                          // even: 8-byte aligned in rows of 4 k floats
+    if (a.rbf == 1) {                                            // (the raw values are the block's residual stream, kept in bf16)
+#pragma unroll
+        for (int r = 0; r < 16; r++) v[r] = bf16_round(v[r]);
+    }
     if (ybu) {
-        if (yu) {
+        if (yu && a.rbf == 2) {
+            uint4 *e = reinterpret_cast<uint4 *>(rbf_packed(a.y, yu) + (((long)(c0 >> 3) * a.y_cs + pos) << 3));
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                const uint2 lo = pack4_bf16(v[p], v[2 + p], v[4 + p], v[6 + p]), hi = pack4_bf16(v[8 + p], v[10 + p], v[12 + p], v[14 + p]);
+                e[p] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            }
+        } else if (yu) {
 #pragma unroll
             for (int j = 0; j < 8; j++) *reinterpret_cast<float2 *>(yu + (long)(c0 + j) * a.y_cs + pos) = make_float2(v[2 * j], v[2 * j + 1]);
         }
@@ -270,7 +292,18 @@ __device__ __forceinline__ void tconv_pt_epilogue(const ConvGemmArgs &a, const f
                 }
         }
         const bool raw_y = ybu || (a.psn_a && y2u);             // y keeps the raw value when the activated one has its own tensor
-        if (yu) {
+        if (a.rbf == 1 && raw_y) {
+#pragma unroll
+            for (int ph = 0; ph < S; ph++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) v[ph][j] = bf16_round(v[ph][j]);
+        }
+        if (yu && a.rbf == 2) {
+            unsigned short *yrb = rbf_packed(a.y, yu);
+#pragma unroll
+            for (int ph = 0; ph < S; ph++)
+                *reinterpret_cast<uint2 *>(yrb + ((((long)(c >> 3) * a.y_cs + pos + ph) << 3) + (c & 4))) = pack4_bf16(v[ph][0], v[ph][1], v[ph][2], v[ph][3]);
+        } else if (yu) {
 #pragma unroll
             for (int j = 0; j < 4; j++)
 #pragma unroll
@@ -346,7 +379,15 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvGemmArgs &a, const 
 #ifndef EPI_ABL
 #define EPI_ABL 0          // timing-only experiments: 1 = no residual loads (zeros), 2 = no fp32 stores beside a packed output
 #endif
-        if (ru) {
+        if (ru && a.rbf == 2) {                   // packed bf16 residual (S == 1 or phase-major rows: host)
+            const unsigned short *rrb = rbf_packed(a.res, ru);
+#pragma unroll
+            for (int g = 0; g < 2; g++) {
+                const int c = cg[g];
+                const uint2 u = *reinterpret_cast<const uint2 *>(rrb + (ok[4 * g] ? ((((long)(c >> 3) * a.y_cs + (long)m * a.S + pg[g]) << 3) + (c & 4)) : 0));
+                unpack4_bf16(u, t + 4 * g);
+            }
+        } else if (ru) {
 #pragma unroll
             for (int q = 0; q < 8; q++) t[q] = (EPI_ABL & 1) ? 0.0f : ru[ok[q] ? ro[q] : 0];
         }
@@ -391,10 +432,19 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvGemmArgs &a, const 
                     w[q] = sv.x; w[q + 1] = sv.y;
                 }
             }
-            if (yu && !(EPI_ABL & 2)) {
+            if (yu && a.rbf == 2) {
+                unsigned short *yrb = rbf_packed(a.y, yu);
+#pragma unroll
+                for (int g = 0; g < 2; g++) {
+                    const int c = cg[g];
+                    if (ok[4 * g])
+                        *reinterpret_cast<uint2 *>(yrb + ((((long)(c >> 3) * a.y_cs + (long)m * a.S + pg[g]) << 3) + (c & 4))) =
+                            pack4_bf16(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+                }
+            } else if (yu && !(EPI_ABL & 2)) {
 #pragma unroll
                 for (int q = 0; q < 8; q++)
-                    if (ok[q]) yu[o[q]] = v[q];
+                    if (ok[q]) yu[o[q]] = a.rbf ? bf16_round(v[q]) : v[q];
             }
             if (a.S == 1 || a.pm) {
 #pragma unroll
@@ -417,8 +467,8 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvGemmArgs &a, const 
                 for (int q = 0; q < 8; q += 2) {
                     f32x2 sv = snake_beta2_t<FAST>(mk2(v[q], v[q + 1]), mk2(Pm[2 * BN + row[q]], Pm[2 * BN + row[q + 1]]),
                                            mk2(Pm[3 * BN + row[q]], Pm[3 * BN + row[q + 1]]));
-                    if (ok[q]) { yu[o[q]] = v[q]; y2u[o[q]] = sv.x; }
-                    if (ok[q + 1]) { yu[o[q + 1]] = v[q + 1]; y2u[o[q + 1]] = sv.y; }
+                    if (ok[q]) { yu[o[q]] = a.rbf ? bf16_round(v[q]) : v[q]; y2u[o[q]] = sv.x; }
+                    if (ok[q + 1]) { yu[o[q + 1]] = a.rbf ? bf16_round(v[q + 1]) : v[q + 1]; y2u[o[q + 1]] = sv.y; }
                 }
             } else {
 #pragma unroll
@@ -432,7 +482,7 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvGemmArgs &a, const 
         } else {
 #pragma unroll
             for (int q = 0; q < 8; q++)
-                if (ok[q]) yu[o[q]] = v[q];
+                if (ok[q]) yu[o[q]] = a.rbf ? bf16_round(v[q]) : v[q];
         }
     }
 }
@@ -451,10 +501,17 @@ __device__ __forceinline__ void fused_epilogue_tile(const ConvGemmArgs &a, const
 #pragma unroll
         for (int q = 0; q < 8; q++) v[q] = resv[half * 8 + q] + (acc2[half * 8 + q] + Pm[3 * BN + n[q]]);
         if (ybu) {     // raw fp32 to yu (if wanted), activated bf16 to the packed tensor
-            if (yu) {
+            if (yu && a.rbf == 2) {
+                unsigned short *yrb = rbf_packed(a.y, yu);
+#pragma unroll
+                for (int g = 0; g < 2; g++)
+                    if (n[4 * g] < a.N && m < a.M)
+                        *reinterpret_cast<uint2 *>(yrb + ((((long)(n[4 * g] >> 3) * a.y_cs + m) << 3) + (n[4 * g] & 4))) =
+                            pack4_bf16(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+            } else if (yu) {
 #pragma unroll
                 for (int q = 0; q < 8; q++)
-                    if (n[q] < a.N && m < a.M) yu[(long)n[q] * a.y_cs + m] = v[q];
+                    if (n[q] < a.N && m < a.M) yu[(long)n[q] * a.y_cs + m] = a.rbf ? bf16_round(v[q]) : v[q];
             }
             if (a.psn_a) {
 #pragma unroll
@@ -481,8 +538,25 @@ __device__ __forceinline__ void fused_epilogue_tile(const ConvGemmArgs &a, const
         }
 #pragma unroll
         for (int q = 0; q < 8; q++)
-            if (n[q] < a.N && m < a.M) yu[(long)n[q] * a.y_cs + m] = v[q];
+            if (n[q] < a.N && m < a.M) yu[(long)n[q] * a.y_cs + m] = (a.rbf && !a.psn_a) ? bf16_round(v[q]) : v[q];
     }
+}
+
+// The residual of one 32-row output tile of a fused unit, as the kernels request it ahead of the 1x1 product: four 8-byte pieces of
+// the packed bf16 stream (ConvGemmArgs::rbf == 2; resu = a.res + unit * y_us) -- register 4g + j of the tile is channel
+// rbase + 8g + j (rbase = 32 o + 4 h) -- unpacked where the epilogue needs the values.
+struct ResPacked { uint2 q[4]; };
+__device__ __forceinline__ void fused_fetch_res_packed(const ConvGemmArgs &a, const float *resu, int rbase, int m, bool ok, ResPacked &d) {     // ok: m < M; N % 8 == 0
+    const unsigned short *rrb = rbf_packed(a.res, resu);
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const int c = rbase + 8 * g;
+        d.q[g] = *reinterpret_cast<const uint2 *>(rrb + ((ok && c < a.N) ? ((((long)(c >> 3) * a.y_cs + m) << 3) + (c & 4)) : 0));
+    }
+}
+__device__ __forceinline__ void fused_unpack_res(const ResPacked &d, float *resv) {
+#pragma unroll
+    for (int g = 0; g < 4; g++) unpack4_bf16(d.q[g], resv + 4 * g);
 }
 
 }  // namespace hipvoc

@@ -128,6 +128,12 @@ struct Ctx {
     bool phase_major = true;   // transposed-conv rows phase-major (HIPVOC_PHASE_MAJOR=0: channel-major)
     bool tconv_oi = true;      // ... octet-interleaved at stride 4 / 8 in the bf16 modes (HIPVOC_TCONV_OI=0: phase-major there too)
     bool packed = true;        // bf16 mode: GEMM-to-GEMM tensors of the decoder stack exchanged as packed bf16 (HIPVOC_PACKED=0: fp32)
+    // bf16 mode, packed exchange: the residual stream of a decoder block in bf16 too (ConvGemmArgs::rbf).  By default in the blocks
+    // whose residual units are single fused launches that exchange the stream through HBM (block 2 of the full model: 0.75 ms of a
+    // 30 ms pass for 0.1 dB); HIPVOC_RES_BF16 = mask, bit b = decoder block b (0: fp32 everywhere -- round 2's arithmetic; 7: blocks
+    // 0 and 1 as well, whose un-fused units gain 0.2 ms each for 0.2 dB each)
+    unsigned res_bf16 = 0;
+    bool res_bf16_auto = true;
     bool wino_tconv = true;    // fp32 mode: the decoder blocks' transposed convs by F(3,2) (HIPVOC_WINO_TCONV=0: direct)
     bool wino_unfuse = true;   // blocks whose residual units could be fused run un-fused when their conv7 has a Winograd form (HIPVOC_WINO_UNFUSE=0)
     bool wino_unit = true;     // fp32 mode: residual units of a 96-channel block as ONE Winograd kernel each (wino_ps_kernel<D,3,true>; HIPVOC_WINO_UNIT=0: the fused direct kernel)
@@ -784,6 +790,7 @@ struct PlanBuilder {
         return (float *)ptr;
     }
 
+    int rbf = 0;                   // ConvGemmArgs::rbf of the NEXT gemm / res_unit_fused step (reset by it)
     void add(const char *name, const char *kernel, double macs, std::function<hipError_t(hipStream_t)> f) {
         p->steps.push_back(Step{std::move(f), name, kernel, macs, 0.0, -1, nullptr, 0, 0, 0});
     }
@@ -797,6 +804,9 @@ struct PlanBuilder {
               const float *res, const float *rscale, int act, const Snake *post = nullptr, float *y2 = nullptr,
               const unsigned short *xb = nullptr, unsigned short *yb = nullptr, int in_elu = 0, int s2d = 0) {
         ConvGemmArgs a{};
+        a.rbf = rbf;
+        const int rb = rbf;
+        rbf = 0;
         a.in_elu = in_elu;
         a.s2d = s2d;
         a.ww = g.ww;
@@ -820,8 +830,8 @@ struct PlanBuilder {
         add(name, conv_gemm_kernel_name(a), macs, [a](hipStream_t s) { return launch_conv_gemm(a, s); });
         {
             const double in_el = (double)g.Cin * G * Lin, out_el = (double)(g.N / g.S) * G * ((double)M * g.S);
-            p->steps.back().bytes = in_el * (xb ? 2 : 4) + (y ? out_el * 4 : 0) + (yb ? out_el * 2 : 0) + (post && y2 ? out_el * 4 : 0) +
-                                    (res ? out_el * 4 : 0);
+            p->steps.back().bytes = in_el * (xb ? 2 : 4) + (y ? out_el * (rb == 2 ? 2 : 4) : 0) + (yb ? out_el * 2 : 0) + (post && y2 ? out_el * 4 : 0) +
+                                    (res ? out_el * (rb == 2 ? 2 : 4) : 0);
         }
     }
 
@@ -835,6 +845,9 @@ struct PlanBuilder {
     void res_unit_fused(const char *name, const Gemm &c1, const Gemm &c2, const Snake &s1, const Snake &s2, const float *x,
                         int L, int Lp, float *y, const Snake *post, const unsigned short *xb = nullptr, unsigned short *yb = nullptr) {
         ConvGemmArgs a{};
+        a.rbf = rbf;
+        const int rb = rbf;
+        rbf = 0;
         a.psn_a = post ? post->ea : nullptr; a.psn_ib = post ? post->ib : nullptr;
         a.x = x; a.y = y; a.w = c1.w; a.wb = c1.wb; a.bias = c1.bias; a.res = x; a.sn_a = s1.ea; a.sn_ib = s1.ib;
         a.xb = xb; a.yb = yb;
@@ -847,7 +860,7 @@ struct PlanBuilder {
         add(name, conv_gemm_kernel_name(a), macs, [a](hipStream_t s) { return launch_conv_gemm(a, s); });
         {
             const double el = (double)c1.N * G * L;      // operand in (packed or fp32), fp32 residual in, fp32 / packed out
-            p->steps.back().bytes = el * (xb ? 2 : 4) + (xb ? el * 4 : 0) + (y ? el * 4 : 0) + (yb ? el * 2 : 0);
+            p->steps.back().bytes = el * (xb ? 2 : 4) + (xb ? el * (rb == 2 ? 2 : 4) : 0) + (y ? el * (rb == 2 ? 2 : 4) : 0) + (yb ? el * 2 : 0);
         }
     }
     // The same residual unit as ONE Winograd kernel (kernels_wino.hip: wino_ps_kernel<D, 3, true>; N = Cin = 96): conv7 by F(2,7),
@@ -1053,7 +1066,15 @@ static std::unique_ptr<Plan> build_plan(Ctx *c, int G, int T, bool debug, char *
             const int L2 = (int)c->tc_len(L, r), Lp2 = rowlen(L2);
             const size_t ni = std::min<size_t>(bi, 4);
             const bool fused_blk = blk_fused(blk);
-            // trans-conv: packed in; fp32 x0 (the residual stream) and packed snake_s1(x0) out
+            // The residual stream of this block in bf16 (ConvGemmArgs::rbf): where the units are separate launches and every one of
+            // them reads and writes the stream through HBM -- not the block that walks along time with the stream in registers
+            // (by capability, not by the HIPVOC_BLK3 switch: both forms of that block keep fp32), nor the block that feeds the
+            // final conv.  Production plans keep it as a packed tensor in the fp32 buffers' memory (2), debug plans as fp32 tensors
+            // that hold the rounded values (1): the same values, so the stage taps show what the production path computes.
+            const bool rbf_on = c->res_bf16_auto ? fused_blk : ((c->res_bf16 >> std::min<size_t>(bi, 31)) & 1u) != 0;
+            const int rbf = (rbf_on && !(blk.ws3 && fused_blk) && bi + 1 < c->blocks.size()) ? (debug ? 1 : 2) : 0;
+            // trans-conv: packed in; x0 (the residual stream) and packed snake_s1(x0) out
+            b.rbf = rbf;
             b.gemm(tcn[ni], blk.tc, nullptr, L, Lp, t1, Lp2, nullptr, nullptr, nullptr, ACT_NONE, &blk.res[0].s1, nullptr, pk[pc],
                    pk[pc ^ 1]);
             std::swap(cur, t1);
@@ -1093,8 +1114,11 @@ static std::unique_ptr<Plan> build_plan(Ctx *c, int G, int T, bool debug, char *
                 const bool last = u == 2 && bi + 1 == c->blocks.size();      // feeds the final conv: fp32 only
                 const Snake *next = u < 2 ? &blk.res[u + 1].s1 : (last ? fin_post : &c->blocks[bi + 1].s);
                 const bool need_f32 = u < 2 || last || debug;                // the residual stream goes on / the final conv
+                // (the third unit's raw output is not part of the stream: nothing but a debug plan's stage tap reads it)
+                const int rbf_u = u < 2 ? rbf : (rbf == 2 ? 2 : 0);
                 if (fused_blk) {
                     unsigned short *ybo = last ? nullptr : pk[pc ^ 1];
+                    b.rbf = rbf_u;
                     b.res_unit_fused(run[ni], ru.c1, ru.c2, ru.s1, ru.s2, cur, L, Lp, need_f32 ? t1 : nullptr, next, pk[pc], ybo);
                     if (need_f32) std::swap(cur, t1);
                     if (ybo) pc ^= 1;
@@ -1103,6 +1127,7 @@ static std::unique_ptr<Plan> build_plan(Ctx *c, int G, int T, bool debug, char *
                            pk[pc ^ 1]);
                     pc ^= 1;
                     unsigned short *ybo = last ? nullptr : pk[pc ^ 1];      // (the unit's input: no longer needed)
+                    b.rbf = rbf_u;
                     b.gemm(c1n[ni], ru.c2, nullptr, L, Lp, need_f32 ? cur : nullptr, Lp, nullptr, cur, nullptr, ACT_NONE, next, nullptr,
                            pk[pc], ybo);
                     if (ybo) pc ^= 1;
@@ -1592,6 +1617,7 @@ static void *load_impl(const char *weights_path, int device_id, int dtype, int u
     if (const char *ps = getenv("HIPVOC_FIN_POST")) c->fin_post = atoi(ps) != 0;
     if (const char *ps = getenv("HIPVOC_DUAL")) c->dual_out = atoi(ps);
     if (const char *ps = getenv("HIPVOC_PACKED")) c->packed = atoi(ps) != 0;
+    if (const char *ps = getenv("HIPVOC_RES_BF16")) { c->res_bf16 = (unsigned)atoi(ps); c->res_bf16_auto = false; }
     if (const char *ps = getenv("HIPVOC_PHASE_MAJOR")) c->phase_major = atoi(ps) != 0;
     if (const char *ps = getenv("HIPVOC_TCONV_OI")) c->tconv_oi = atoi(ps) != 0;
     if (const char *ps = getenv("HIPVOC_WINO")) c->wino = atoi(ps) != 0;

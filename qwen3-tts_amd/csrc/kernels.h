@@ -73,6 +73,11 @@ struct ConvGemmArgs {
                                      // element (c, m) goes to channel c*s2d + m % s2d, position m / s2d (y_cs / y_us are the
                                      // strides of THAT tensor; M must be a multiple of s2d); the residual keeps x's strides
     int dbg;                         // timing-only ablation bits (set by the launcher from HIPVOC_DBG; 0 in production)
+    // bf16 mode, residual stream in bf16 (HIPVOC_RES_BF16, hipvoc.cpp): the RAW output of this step is the residual stream of a
+    // decoder block and is rounded to bf16 where it is written.  1: y / res are fp32 tensors that hold the rounded values (debug
+    // plans, the fp32 exchange); 2: y and res POINT TO packed bf16 tensors in the layout and strides of yb (the float types of the
+    // two fields are then nominal; needs yb, (N/S) % 8 == 0, S == 1 or pm != 0).  Same values either way, bit for bit.
+    int rbf;
 };
 hipError_t launch_conv_gemm(const ConvGemmArgs &a, hipStream_t s);
 hipError_t launch_conv_gemm_bf16(const ConvGemmArgs &a, hipStream_t s);

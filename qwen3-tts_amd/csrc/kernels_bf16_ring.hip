@@ -499,7 +499,8 @@ constexpr int NTAPS = 7;
 static_assert(4 * XW % (64 * NW) == 0, "every wave issues the same number of activation pieces");
 }  // namespace ringu
 
-template <int TN>
+// RB: the residual stream is the packed bf16 tensor (ConvGemmArgs::rbf == 2): four 8-byte loads per tile instead of sixteen 4-byte ones
+template <int TN, bool RB>
 __global__ __launch_bounds__(ringu::NTH, 2) void resunit_bf16_ring_kernel(ConvGemmArgs a, int tiles_per_unit) {
     using namespace ringu;
     constexpr int BN = 32 * TN;
@@ -634,12 +635,18 @@ __global__ __launch_bounds__(ringu::NTH, 2) void resunit_bf16_ring_kernel(ConvGe
     // the residual of output tile o: sixteen unconditional loads from a clamped position (N == BN: every row exists), requested one
     // tile AHEAD; tile 0's before the SnakeBeta pass below
     const float *rup = a.res + (long)unit * a.y_us + (m < a.M ? m : a.M - 1) + (long)(4 * h) * a.y_cs;
-    auto fetch_res = [&](int o, float *dst) {
+    const float *rupk = a.res + (long)unit * a.y_us;
+    float resv[RB ? 1 : 2][16];
+    ResPacked resq[RB ? 2 : 1];
+    auto fetch_res = [&](int o) {
+        if constexpr (RB) {
+            fused_fetch_res_packed(a, rupk, o * 32 + 4 * h, m < a.M ? m : a.M - 1, true, resq[o & 1]);
+        } else {
 #pragma unroll
-        for (int r = 0; r < 16; r++) dst[r] = rup[(long)(o * 32 + (r & 3) + 8 * (r >> 2)) * a.y_cs];
+            for (int r = 0; r < 16; r++) resv[o & 1][r] = rup[(long)(o * 32 + (r & 3) + 8 * (r >> 2)) * a.y_cs];
+        }
     };
-    float resv[2][16];
-    fetch_res(0, resv[0]);
+    fetch_res(0);
     // the first output tile's weights (slot nstage: certified by the last stage's barrier) are read under the SnakeBeta pass too
     const unsigned w2addr0 = w_lds + (unsigned)lane * 16u;
     rg_bf16x8 w2q[2][2 * TN];
@@ -679,7 +686,7 @@ __global__ __launch_bounds__(ringu::NTH, 2) void resunit_bf16_ring_kernel(ConvGe
         if (o + 2 < TN) rg_wait_bar<WP>();
         else rg_wait_bar<0>();
         if (o + 3 < TN) dma_w(st + 3, (st + 3) & (RW - 1));
-        if (o + 1 < TN) fetch_res(o + 1, resv[(o + 1) & 1]);
+        if (o + 1 < TN) fetch_res(o + 1);
         asm volatile("" ::: "memory");
         if (o + 1 < TN) {
 #pragma unroll
@@ -694,7 +701,12 @@ __global__ __launch_bounds__(ringu::NTH, 2) void resunit_bf16_ring_kernel(ConvGe
 #pragma unroll
             for (int g = 0; g < 2; g++) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2q[o & 1][i * 2 + g], hb[i][g], acc2, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        fused_epilogue_tile<BN, true>(a, acc2, resv[o & 1], Pm, o * 32 + 4 * h, m, yu, ybu);
+        if constexpr (RB) {
+            fused_unpack_res(resq[o & 1], resv[0]);
+            fused_epilogue_tile<BN, true>(a, acc2, resv[0], Pm, o * 32 + 4 * h, m, yu, ybu);
+        } else {
+            fused_epilogue_tile<BN, true>(a, acc2, resv[o & 1], Pm, o * 32 + 4 * h, m, yu, ybu);
+        }
     }
 }
 
@@ -952,7 +964,7 @@ static bool resunit_ring_selected(const ConvGemmArgs &a) {
 bool conv_bf16_ring_selected(const ConvGemmArgs &a) { return conv7_bf16_ring_selected(a) || tconv_ring_selected(a) || resunit_ring_selected(a); }
 
 const char *conv_bf16_ring_kernel_name(const ConvGemmArgs &a) {
-    if (resunit_ring_selected(a)) return "resunit_bf16_ring_kernel<6>";
+    if (resunit_ring_selected(a)) return a.rbf == 2 ? "resunit_bf16_ring_kernel<6,true>" : "resunit_bf16_ring_kernel<6,false>";
     if (tconv_ring_selected(a)) return a.pm == 2 ? "conv_bf16_ring_kernel<4,2,2,4>" : "conv_bf16_ring_kernel<5,2,3,3>";
     const int m = ring_mode();
     return m == 1 ? "conv7_bf16_ring_kernel<4>" : (m == 2 ? "conv7_bf16_ring8_kernel<4,8,2>" : "conv_bf16_ring_kernel<4,7,0,4>");
@@ -986,6 +998,9 @@ hipError_t launch_conv_bf16_ring(const ConvGemmArgs &a, hipStream_t s) {
     if (((uintptr_t)a.wb & 15) || ((uintptr_t)a.xb & 15) || (a.yb && ((uintptr_t)a.yb & 15)) || (!a.y && !a.yb) || (a.yb && ((a.N / a.S) & 7)) ||
         (a.y2 && (!a.psn_a || !a.psn_ib || a.yb)) || a.NP < a.N)
         return hipErrorInvalidValue;
+    if (a.rbf == 2 && (((a.N / a.S) & 7) || (a.N % a.S) || (a.S > 1 && !a.pm) || (a.y && ((uintptr_t)a.y & 15)) || (a.res && ((uintptr_t)a.res & 15)) ||
+                       (a.y && !a.yb) || a.y2))
+        return hipErrorInvalidValue;
     if (resunit_ring_selected(a)) {
         using namespace ringu;
         if (((uintptr_t)a.wb2 & 15) || (a.yb && !a.psn_a) || (a.psn_a && !a.psn_ib)) return hipErrorInvalidValue;
@@ -999,11 +1014,14 @@ hipError_t launch_conv_bf16_ring(const ConvGemmArgs &a, hipStream_t s) {
         hipError_t e = hipGetDevice(&dev);
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64 && !doneu[dev]) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(resunit_bf16_ring_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(resunit_bf16_ring_kernel<6, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void *>(resunit_bf16_ring_kernel<6, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
             doneu[dev] = true;
         }
-        hipLaunchKernelGGL(resunit_bf16_ring_kernel<6>, dim3((unsigned)grid), dim3(NTH), lds, s, a, tiles_per_unit);
+        if (a.rbf == 2) hipLaunchKernelGGL((resunit_bf16_ring_kernel<6, true>), dim3((unsigned)grid), dim3(NTH), lds, s, a, tiles_per_unit);
+        else hipLaunchKernelGGL((resunit_bf16_ring_kernel<6, false>), dim3((unsigned)grid), dim3(NTH), lds, s, a, tiles_per_unit);
         return hipGetLastError();
     }
     if (tconv_ring_selected(a)) {

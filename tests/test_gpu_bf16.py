@@ -136,23 +136,27 @@ def test_bf16_deterministic(pkg, synth):
 def test_bf16_packed_dataflow_equals_fp32_exchange_bitwise(pkg, synth, cfg_name, unit, frames):
     """Production bf16 plans exchange GEMM-to-GEMM tensors of the decoder stack as packed bf16 with the consumer's
     SnakeBeta applied by the producer (ConvGemmArgs::xb / yb); HIPVOC_PACKED=0 keeps them fp32 and rounds in the
-    consumer.  Same fp32 values rounded at the same point: the waveforms must be identical."""
+    consumer.  Same fp32 values rounded at the same point: the waveforms must be identical.  (With the residual stream in fp32
+    on both sides, HIPVOC_RES_BF16=0: the fp32 exchange has no bf16 stream, see test_bf16_residual_stream_in_bf16.)"""
     cfg = getattr(synth, cfg_name)
     path = os.path.join(tempfile.gettempdir(), f"hipvoc_test_{cfg_name}_0.safetensors")
     if not os.path.exists(path):
         synth.save_safetensors(path, weights_for(synth, cfg_name, 0), cfg.metadata())
     codes = synth.make_codes(frames, 11, cfg)
     old = os.environ.get("HIPVOC_PACKED")
+    old_rb = os.environ.get("HIPVOC_RES_BF16")
     try:
+        os.environ["HIPVOC_RES_BF16"] = "0"
         os.environ["HIPVOC_PACKED"] = "0"
         plain = pkg.HipVocoder.load(path, device=0, unit_frames=unit, dtype=BF16)
         os.environ["HIPVOC_PACKED"] = "1"
         packed = pkg.HipVocoder.load(path, device=0, unit_frames=unit, dtype=BF16)
     finally:
-        if old is None:
-            os.environ.pop("HIPVOC_PACKED", None)
-        else:
-            os.environ["HIPVOC_PACKED"] = old
+        for k, o in (("HIPVOC_PACKED", old), ("HIPVOC_RES_BF16", old_rb)):
+            if o is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = o
     a = plain.synthesize(codes)
     b = packed.synthesize(codes)
     assert a.size == b.size and a.size > 0
@@ -346,7 +350,7 @@ def test_bf16_resunit_ring_kernel_bitwise(pkg, synth, unit, frames, n_seq, monke
         synth.save_safetensors(path, weights_for(synth, "FULL", 0), cfg.metadata())
     seqs = [synth.make_codes(frames, 377 + i, cfg) for i in range(n_seq)]
     outs = []
-    for mode, name in (("0", None), ("1", "resunit_bf16_ring_kernel<6>")):
+    for mode, name in (("0", None), ("1", "resunit_bf16_ring_kernel<6,true>")):
         monkeypatch.setenv("HIPVOC_BF16_RING_UNIT", mode)         # read at every launch
         v = pkg.HipVocoder.load(path, device=0, unit_frames=unit, dtype=BF16)
         v.set_profile(True)
@@ -395,3 +399,42 @@ def test_two_lanes_of_one_handle_bitwise_and_ordered(pkg, synth, dtype, n_units,
     assert host[0].size > 1800 * sum(len(q) for q in seqs) and np.array_equal(host[0].view(np.uint32), host[1].view(np.uint32))
     assert len(pcm[0]) == 2 * host[0].size and pcm[0] == pcm[1]
     assert np.array_equal(outs[1][0, : n_units - 70].view(np.uint32), outs[1][1, : n_units - 70].view(np.uint32))
+
+
+@pytest.mark.parametrize("cfg_name,unit,frames", [("FULL", 8, 8), ("FULL", 64, 61), ("SMALL", 10, 10), ("PAD8", 7, 5)])
+def test_bf16_residual_stream_in_bf16(pkg, synth, vo, cfg_name, unit, frames, monkeypatch):
+    """bf16 mode, packed exchange: the residual stream of the decoder blocks whose residual units are single fused launches that
+    exchange it through HBM (block 2 of the full model; HIPVOC_RES_BF16=7: blocks 0 and 1 too, =0: fp32 everywhere as in round 2) is
+    rounded to bf16 wherever it is written and kept as a packed tensor (ConvGemmArgs::rbf).  (a) The debug plans keep the stream as fp32 tensors that hold the rounded values: their last stage is the production
+    waveform bit for bit (both forms of every epilogue round at the same point).  (b) What the rounding costs: the two waveforms agree
+    to 35 dB or better (40 dB on the full model), and each is inside the mode's gate against the fp32 oracle."""
+    cfg = getattr(synth, cfg_name)
+    path = os.path.join(tempfile.gettempdir(), f"hipvoc_test_{cfg_name}_0.safetensors")
+    if not os.path.exists(path):
+        synth.save_safetensors(path, weights_for(synth, cfg_name, 0), cfg.metadata())
+    codes = synth.make_codes(frames, 77, cfg)
+    padded = np.zeros((unit, codes.shape[1]), dtype=np.int64)
+    padded[:frames] = codes
+    ref = oracle_for(vo, synth, cfg_name, 0).synthesize(codes, unit)
+    outs = {}
+    for rb in ("auto", "7", "0"):                                  # the default (fused-unit blocks: block 2), every eligible block, none
+        if rb == "auto":
+            monkeypatch.delenv("HIPVOC_RES_BF16", raising=False)
+        else:
+            monkeypatch.setenv("HIPVOC_RES_BF16", rb)              # read at load
+        v = pkg.HipVocoder.load(path, device=0, unit_frames=unit, dtype=BF16)
+        got = v.synthesize(codes)
+        whole = v.run(padded)                                       # the whole padded unit, as the last stage holds it
+        last = v.stage(padded, v.n_stages - 1, whole.size + 8)
+        assert np.array_equal(last.reshape(-1).view(np.uint32), whole.reshape(-1).view(np.uint32)), (rb, float(np.abs(last.reshape(-1) - whole.reshape(-1)).max()))
+        assert got.size == ref.size and snr_db(ref, got) >= WAV_SNR_DB and np.abs(got - ref).max() <= WAV_MAX_ABS, (rb, snr_db(ref, got))
+        if cfg_name == "FULL":
+            v.set_profile(True)
+            v.synthesize(codes)
+            names = sorted(v.last_profile())
+            assert any("resunit_bf16_ring_kernel<6,true>" in k for k in names) == (rb != "0"), names
+        outs[rb] = got
+        v.close()
+    print(f"{cfg_name} T={unit}: bf16 stream (default / all blocks) vs fp32 stream {snr_db(outs['0'], outs['auto']):.1f} / {snr_db(outs['0'], outs['7']):.1f} dB; "
+          f"vs the fp32 oracle {snr_db(ref, outs['auto']):.2f} / {snr_db(ref, outs['7']):.2f} / {snr_db(ref, outs['0']):.2f} dB")
+    assert snr_db(outs["0"], outs["auto"]) >= 35.0 and snr_db(outs["0"], outs["7"]) >= 35.0

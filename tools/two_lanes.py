@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Do two independent passes overlap usefully on one GPU?  One handle decoding N units (passes back to back on its stream) against
-TWO handles (own stream, own workspace) decoding N/2 each at the same time.  `two_lanes.py [f32|bf16] [units]`"""
+TWO handles (own stream, own workspace) decoding N/2 each at the same time.  `two_lanes.py [f32|bf16] [units] [K]`; with K > 2
+also K handles taking the passes in turn.  (The handles are loaded with one lane each: HIPVOC_LANES=1.)"""
 import os, sys, tempfile, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,6 +16,8 @@ if not os.path.exists(path):
     synth.save_safetensors(path, synth.make_weights(cfg, 0), cfg.metadata())
 dt = {"f32": 0, "bf16": 1, "bf16x3": 2}[sys.argv[1] if len(sys.argv) > 1 else "f32"]
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+K = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+os.environ["HIPVOC_LANES"] = "1"
 va = pkg.HipVocoder.load(path, unit_frames=64, dtype=dt)
 vb = pkg.HipVocoder.load(path, unit_frames=64, dtype=dt)
 codes = np.stack([synth.make_codes(64, 1000 + i, cfg) for i in range(N)])
@@ -37,7 +40,16 @@ def two_interleaved():                      # pass by pass, alternating handles:
         v = va if k % 2 == 0 else vb
         v.decode_units_device(d_codes.data_ptr() + u0 * cb, min(G, N - u0), d_out.data_ptr() + u0 * stride * 4, stride)
     va.sync(); vb.sync()
-for name, fn in (("one handle", one), ("two handles, halves", two), ("two handles, alternating passes", two_interleaved), ("one handle", one)):
+extra = [pkg.HipVocoder.load(path, unit_frames=64, dtype=dt) for _ in range(K - 2)]
+def k_interleaved():
+    hs = [va, vb] + extra
+    G = va.group_units
+    for k, u0 in enumerate(range(0, N, G)):
+        hs[k % K].decode_units_device(d_codes.data_ptr() + u0 * cb, min(G, N - u0), d_out.data_ptr() + u0 * stride * 4, stride)
+    for v in hs: v.sync()
+cases = [("one handle", one), ("two handles, halves", two), ("two handles, alternating passes", two_interleaved)]
+if K > 2: cases.append((f"{K} handles, alternating passes", k_interleaved))
+for name, fn in cases + [("one handle", one)]:
     fn(); fn()
     t = time.perf_counter()
     for _ in range(3): fn()
