@@ -396,7 +396,9 @@ def main(argv=None):
             L *= r
             dw_bytes += 2 * cfg.latent_dim * L * 4 * G                 # x in, normalised y out
         alg = {
-            next((k for k in kernels if k.startswith("final_conv_kernel")), "final_conv_kernel<7,false>"): G * (cfg.decoder_dim // 16 * Lu + Lu) * 4,   # C=96 activations in, 1 channel out
+            # C = 96 activations in (fp32, or the bf16 mode's packed bf16 tensor), 1 channel out
+            next((k for k in kernels if k.startswith("final_conv")), "final_conv_kernel<7,false>"):
+                G * (cfg.decoder_dim // 16 * Lu * (2 if any(k.startswith("final_conv_packed") for k in kernels) else 4) + Lu * 4),
             next((k for k in kernels if k.startswith("dwconv_ln")), "dwconv_ln_kernel"): dw_bytes,
             next((k for k in kernels if k.startswith("rmsnorm")), "rmsnorm_kernel"): (2 * cfg.num_hidden_layers + 1) * 2 * cfg.hidden_size * G * T * 4,
             "swiglu_kernel": cfg.num_hidden_layers * 3 * cfg.intermediate_size * G * T * 4,
@@ -458,7 +460,10 @@ def main(argv=None):
                         f"(125 frames x 16 codebooks -> 2 reference units of 64 frames each)")
             conf = {"workload": workload, "utterances_per_gpu": args.utterances, "units_per_gpu": n_units}
         conf["workload"] += f", {MODE_TEXT[args.dtype]}, seeded random-init weights of the Qwen3-TTS 12 Hz decoder (114 M params)"
-        conf.update({"unit_frames": T, "units_per_pass": voc.group_units})
+        conf.update({"unit_frames": T, "units_per_pass": voc.group_units, "lanes": getattr(voc, "lanes", 1)})
+        if getattr(voc, "lanes", 1) > 1 and roofline:
+            roofline["note_lanes"] = ("the timed steps run with two passes in flight (HIPVOC_LANES=2: alternate passes on two streams, a workspace each); "
+                                      "the per-kernel durations here are one lane's, from one profiled pass -- compare with a rocprofv3 summary taken at HIPVOC_LANES=1")
         line = {
             "metric": "vocoder audio-sec/sec (xRT)", "value": round(value, 2), "unit": "audio-sec/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

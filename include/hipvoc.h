@@ -166,6 +166,11 @@ void *hipvoc_stream(void *h);
 /* Units decoded per pass (workspace is sized for this many; default 64, env HIPVOC_GROUP). */
 int hipvoc_group_units(void *h);
 
+/* Lanes of the handle (1 or 2): passes of one call that may be in flight side by side, each with a stream and a workspace of its
+ * own (see hipvoc_decode_units_device; env HIPVOC_LANES, read by hipvoc_load).  No counterpart in the reference: a report for
+ * benchmarks and capacity planning (a second lane is a second workspace). */
+int hipvoc_lanes(void *h);
+
 /* Algorithmic work of one unit, recomputed from the loaded tensor shapes:
  * multiply-accumulates of all GEMM-shaped stages. */
 int64_t hipvoc_unit_macs(void *h);

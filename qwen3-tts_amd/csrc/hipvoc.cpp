@@ -134,6 +134,9 @@ struct Ctx {
     // 0 and 1 as well, whose un-fused units gain 0.2 ms each for 0.2 dB each)
     unsigned res_bf16 = 0;
     bool res_bf16_auto = true;
+    // bf16 mode, packed exchange: the final conv filters the packed bf16 tensor of its activated input (written by the last residual
+    // unit) instead of an fp32 one -- the operand rounding every other conv of the mode has (HIPVOC_FIN_BF16=0: fp32)
+    bool fin_bf16 = true;
     bool wino_tconv = true;    // fp32 mode: the decoder blocks' transposed convs by F(3,2) (HIPVOC_WINO_TCONV=0: direct)
     bool wino_unfuse = true;   // blocks whose residual units could be fused run un-fused when their conv7 has a Winograd form (HIPVOC_WINO_UNFUSE=0)
     bool wino_unit = true;     // fp32 mode: residual units of a 96-channel block as ONE Winograd kernel each (wino_ps_kernel<D,3,true>; HIPVOC_WINO_UNIT=0: the fused direct kernel)
@@ -1043,6 +1046,11 @@ static std::unique_ptr<Plan> build_plan(Ctx *c, int G, int T, bool debug, char *
     // residual stream stays fp32.  Needs every channel count of the stack to be a multiple of 8.
     bool packed = c->bf16 && !c->split3 && c->packed && !c->blocks.empty() && c->dec_dim % 8 == 0;
     for (size_t i = 0; packed && i < c->blocks.size(); i++) packed = (c->blocks[i].tc.N / c->rates[i]) % 8 == 0;
+    // the final conv's input as a packed bf16 tensor: production plans get it from the last unit (fin_pk), debug plans -- whose
+    // final kernel applies the SnakeBeta itself to the raw fp32 tensor -- round there (fin_round): the same values
+    const bool fin_b = packed && c->fin_bf16 && c->fin.ntaps == 7 && c->fin.Cin % 8 == 0;
+    const unsigned short *fin_pk = nullptr;
+    const bool fin_round = fin_b && !fin_post;
     if (packed) {
         unsigned short *pk[2] = {reinterpret_cast<unsigned short *>(b.buf(B_PK0, big / 2 + 64)),
                                  reinterpret_cast<unsigned short *>(b.buf(B_PK1, big / 2 + 64))};
@@ -1087,8 +1095,9 @@ static std::unique_ptr<Plan> build_plan(Ctx *c, int G, int T, bool debug, char *
                 const bool lastb = bi + 1 == c->blocks.size();
                 ResBlock3Args a{};
                 a.xb = pk[pc]; a.x = cur; a.ws = blk.ws3;
-                a.y = lastb ? t1 : nullptr;
-                a.yb = lastb ? nullptr : pk[pc ^ 1];
+                const bool to_fin = lastb && fin_b && fin_post;        // the final conv takes the packed activated tensor
+                a.y = (lastb && !to_fin) ? t1 : nullptr;
+                a.yb = (lastb && !to_fin) ? nullptr : pk[pc ^ 1];
                 for (int u = 0; u < 3; u++) {
                     const Ctx::Res &ru = blk.res[u];
                     const Snake *next = u < 2 ? &blk.res[u + 1].s1 : (lastb ? fin_post : &c->blocks[bi + 1].s);
@@ -1102,10 +1111,11 @@ static std::unique_ptr<Plan> build_plan(Ctx *c, int G, int T, bool debug, char *
                 b.add(rbn[ni], "resblock3_bf16_kernel", macs, [a](hipStream_t s) { return launch_resblock3_bf16(a, s); });
                 {
                     const double el = (double)C * G * L;             // packed operand + fp32 residual in, fp32 or packed out
-                    b.p->steps.back().bytes = el * (2 + 4) + el * (lastb ? 4 : 2);
+                    b.p->steps.back().bytes = el * (2 + 4) + el * ((lastb && !to_fin) ? 4 : 2);
                 }
-                if (lastb) std::swap(cur, t1); else pc ^= 1;
-                if (lastb) b.mark(st + 2, cur, C, L, Lp);
+                if (lastb && !to_fin) std::swap(cur, t1); else pc ^= 1;
+                if (lastb && !to_fin) b.mark(st + 2, cur, C, L, Lp);
+                if (to_fin) fin_pk = pk[pc];
                 st += 3;
                 continue;
             }
@@ -1113,24 +1123,27 @@ static std::unique_ptr<Plan> build_plan(Ctx *c, int G, int T, bool debug, char *
                 const Ctx::Res &ru = blk.res[u];
                 const bool last = u == 2 && bi + 1 == c->blocks.size();      // feeds the final conv: fp32 only
                 const Snake *next = u < 2 ? &blk.res[u + 1].s1 : (last ? fin_post : &c->blocks[bi + 1].s);
-                const bool need_f32 = u < 2 || last || debug;                // the residual stream goes on / the final conv
+                const bool to_fin = last && fin_b && fin_post;               // the final conv takes the packed activated tensor
+                const bool need_f32 = u < 2 || (last && !to_fin) || debug;   // the residual stream goes on / the final conv
                 // (the third unit's raw output is not part of the stream: nothing but a debug plan's stage tap reads it)
                 const int rbf_u = u < 2 ? rbf : (rbf == 2 ? 2 : 0);
                 if (fused_blk) {
-                    unsigned short *ybo = last ? nullptr : pk[pc ^ 1];
+                    unsigned short *ybo = (last && !to_fin) ? nullptr : pk[pc ^ 1];
                     b.rbf = rbf_u;
                     b.res_unit_fused(run[ni], ru.c1, ru.c2, ru.s1, ru.s2, cur, L, Lp, need_f32 ? t1 : nullptr, next, pk[pc], ybo);
                     if (need_f32) std::swap(cur, t1);
                     if (ybo) pc ^= 1;
+                    if (to_fin) fin_pk = pk[pc];
                 } else {
                     b.gemm(c7n[ni], ru.c1, nullptr, L, Lp, nullptr, Lp, nullptr, nullptr, nullptr, ACT_NONE, &ru.s2, nullptr, pk[pc],
                            pk[pc ^ 1]);
                     pc ^= 1;
-                    unsigned short *ybo = last ? nullptr : pk[pc ^ 1];      // (the unit's input: no longer needed)
+                    unsigned short *ybo = (last && !to_fin) ? nullptr : pk[pc ^ 1];      // (the unit's input: no longer needed)
                     b.rbf = rbf_u;
                     b.gemm(c1n[ni], ru.c2, nullptr, L, Lp, need_f32 ? cur : nullptr, Lp, nullptr, cur, nullptr, ACT_NONE, next, nullptr,
                            pk[pc], ybo);
                     if (ybo) pc ^= 1;
+                    if (to_fin) fin_pk = pk[pc];
                 }
                 if (need_f32) b.mark(st, cur, C, L, Lp);
                 st++;
@@ -1204,10 +1217,20 @@ static std::unique_ptr<Plan> build_plan(Ctx *c, int G, int T, bool debug, char *
         int Cf = g.Cin, GG = G, LL = L, LLp = Lp;
         Ctx *cc = c;
         const bool hw_snake = c->bf16 && !c->split3;             // the bf16 mode evaluates every SnakeBeta in its hardware form (device_common.h)
-        b.add("final_conv7", sa ? (hw_snake ? "final_conv_kernel<7,true,true>" : "final_conv_kernel<7,true>") : "final_conv_kernel<7,false>", (double)G * L * g.Cin * g.ntaps, [=](hipStream_t s) {
-            return launch_final_conv(x, cc->cur_out, w, bias, sa, sib, Cf, 7, GG, LL, LLp, cc->cur_out_stride, s, hw_snake);
-        });
-        plan->steps.back().bytes = ((double)g.Cin + 1.0) * G * L * 4;
+        if (fin_pk) {
+            const unsigned short *xbk = fin_pk;
+            b.add("final_conv7", "final_conv_packed_kernel<7>", (double)G * L * g.Cin * g.ntaps, [=](hipStream_t s) {
+                return launch_final_conv_packed(xbk, cc->cur_out, w, bias, Cf, 7, GG, LL, LLp, cc->cur_out_stride, s);
+            });
+            plan->steps.back().bytes = ((double)g.Cin * 2 + 4.0) * G * L;
+        } else {
+            const bool rnd = fin_round && sa && hw_snake;
+            b.add("final_conv7", sa ? (rnd ? "final_conv_kernel<7,true,true,true>" : hw_snake ? "final_conv_kernel<7,true,true>" : "final_conv_kernel<7,true>") : "final_conv_kernel<7,false>",
+                  (double)G * L * g.Cin * g.ntaps, [=](hipStream_t s) {
+                return launch_final_conv(x, cc->cur_out, w, bias, sa, sib, Cf, 7, GG, LL, LLp, cc->cur_out_stride, s, hw_snake, rnd);
+            });
+            plan->steps.back().bytes = ((double)g.Cin + 1.0) * G * L * 4;
+        }
         b.mark(st++, nullptr, 1, L, 0);
     } else {
         ConvGemmArgs a{};
@@ -1618,6 +1641,7 @@ static void *load_impl(const char *weights_path, int device_id, int dtype, int u
     if (const char *ps = getenv("HIPVOC_DUAL")) c->dual_out = atoi(ps);
     if (const char *ps = getenv("HIPVOC_PACKED")) c->packed = atoi(ps) != 0;
     if (const char *ps = getenv("HIPVOC_RES_BF16")) { c->res_bf16 = (unsigned)atoi(ps); c->res_bf16_auto = false; }
+    if (const char *ps = getenv("HIPVOC_FIN_BF16")) c->fin_bf16 = atoi(ps) != 0;
     if (const char *ps = getenv("HIPVOC_PHASE_MAJOR")) c->phase_major = atoi(ps) != 0;
     if (const char *ps = getenv("HIPVOC_TCONV_OI")) c->tconv_oi = atoi(ps) != 0;
     if (const char *ps = getenv("HIPVOC_WINO")) c->wino = atoi(ps) != 0;
@@ -1684,6 +1708,7 @@ int hipvoc_max_tokens(void *h) { return h ? ((Ctx *)h)->unit_frames : HIPVOC_E_A
 int hipvoc_n_codebooks(void *h) { return h ? ((Ctx *)h)->n_q : HIPVOC_E_ARG; }
 int64_t hipvoc_unit_samples(void *h) { return h ? ((Ctx *)h)->out_len(((Ctx *)h)->unit_frames) : HIPVOC_E_ARG; }
 int hipvoc_group_units(void *h) { return h ? ((Ctx *)h)->group : HIPVOC_E_ARG; }
+int hipvoc_lanes(void *h) { return h ? ((Ctx *)h)->lanes : HIPVOC_E_ARG; }
 int64_t hipvoc_unit_macs(void *h) { return h ? ((Ctx *)h)->unit_macs : HIPVOC_E_ARG; }
 void *hipvoc_stream(void *h) { return h ? (void *)((Ctx *)h)->stream : nullptr; }
 

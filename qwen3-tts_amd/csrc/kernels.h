@@ -177,7 +177,12 @@ const char *dwconv_ln_kernel_name(int C, int K);
 
 // Final stage: SnakeBeta -> causal conv C->1 (w[C][K], K == 7; other K: use conv_gemm) -> clamp; out[u*out_stride + t]
 hipError_t launch_final_conv(const float *x, float *out, const float *w, const float *bias, const float *sn_a,
-                             const float *sn_ib, int C, int K, int G, int L, int Lp, long out_stride, hipStream_t s, bool fast_snake = false);
+                             const float *sn_ib, int C, int K, int G, int L, int Lp, long out_stride, hipStream_t s, bool fast_snake = false,
+                             bool round_act = false);
+// bf16 mode: the final conv over the packed bf16 tensor of the ACTIVATED input ([C/8][G][Lp] 16-byte elements; C % 8 == 0);
+// round_act above is its twin on the raw fp32 tensor (SnakeBeta in the bf16 mode's form, rounded to bf16, same fma chains)
+hipError_t launch_final_conv_packed(const unsigned short *xb, float *out, const float *w, const float *bias, int C, int K, int G, int L, int Lp,
+                                    long out_stride, hipStream_t s);
 
 // f32 -> i16 PCM: (s*32767.0).clamp(-32768.0, 32767.0) as i16   (src/worker/mod.rs:521-524)
 hipError_t launch_pcm16(const float *x, int16_t *y, long n, hipStream_t s);

@@ -1102,10 +1102,12 @@ hipError_t launch_dwconv_ln(const float *x, float *y, const float *dw_w, const f
 // sn_a == null: x is already activated (the last residual unit applied the final SnakeBeta in its epilogue, once per
 // element instead of 2.5 times here) and the kernel is a plain 7-tap filter over C rows.
 // -------------------------------------------------------------------------------------------------
-template <int K, bool SN, bool FAST = false>      // SN: x is the raw tensor and the kernel applies the SnakeBeta itself (a compile-time choice: as a run-time
+template <int K, bool SN, bool FAST = false, bool RND = false>      // SN: x is the raw tensor and the kernel applies the SnakeBeta itself (a compile-time choice: as a run-time
                                 // branch in the channel loop it kept hipcc from issuing the next channels' loads ahead of the arithmetic)
                                 // FAST: ... in the bf16 mode's form (device_common.h: snake_beta2_hw), so that WHERE the final activation
                                 // is applied (HIPVOC_FIN_POST) changes no bit in that mode either
+                                // RND: ... and rounded to bf16, as the producer does when it hands the activated tensor over packed
+                                // (final_conv_packed_kernel below): same values, same chain of fmas, same bits
 __global__ __launch_bounds__(256) void final_conv_kernel(const float *x, float *out, const float *w /*[C][K]*/,
                                                           const float *bias, const float *sn_a, const float *sn_ib,
                                                           int C, int G, int L, int Lp, long out_stride,
@@ -1155,6 +1157,7 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const float *x, float *
 #pragma unroll
                 for (int i = 2; i < 12; i += 2) {         // (sv[0], sv[1] are never read: K - 1 <= 6)
                     f32x2 s2 = snake_beta2_t<FAST>(mk2(sv[i], sv[i + 1]), sa, sib);
+                    if constexpr (RND) s2 = mk2(bf16_round(s2.x), bf16_round(s2.y));
                     int pos = t - 8 + i;
                     sv[i] = (pos >= 0 && pos < L) ? s2.x : 0.0f;        // zero padding applies to the activation output
                     sv[i + 1] = (pos + 1 >= 0 && pos + 1 < L) ? s2.y : 0.0f;
@@ -1180,14 +1183,96 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const float *x, float *
     }
 }
 
+// bf16 mode: the same filter over the PACKED activated tensor (16-byte elements [C/8][G][Lp] of eight bf16 channels, written by the
+// last residual unit): half the bytes of this HBM-bound stage, ten 16-byte loads per eight channels where the fp32 form issues
+// twenty-four.  Channels and taps in the fp32 kernel's order: one chain of fmas per sample, the same bits as
+// final_conv_kernel<7, true, true, true> on the raw tensor.
+template <int K>
+__global__ __launch_bounds__(256) void final_conv_packed_kernel(const uint4 *xb, float *out, const float *w /*[C][K]*/, const float *bias,
+                                                                 int C, int G, int L, int Lp, long out_stride, int vec_store) {
+    constexpr int NO = 4, NP = NO + K - 1;               // positions t - (K-1) .. t + 3
+    int t = (blockIdx.x * 256 + threadIdx.x) * NO;
+    int u = blockIdx.y;
+    if (t >= L) return;
+    const long cs = (long)G * Lp;
+    const uint4 *xu = xb + (long)u * Lp;
+    float acc[NO];
+    const float b0 = bias ? bias[0] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < NO; i++) acc[i] = b0;
+    constexpr int GB = 2;                                // channel groups per batch: all loads of a batch before its arithmetic
+    const int ng = C >> 3;                               // (host: C % 8 == 0)
+    for (int g0 = 0; g0 < ng; g0 += GB) {
+        uint4 e[GB][NP];
+#pragma unroll
+        for (int q = 0; q < GB; q++) {
+            const int g = g0 + q < ng ? g0 + q : ng - 1;
+            const uint4 *xr = xu + (long)g * cs;
+#pragma unroll
+            for (int i = 0; i < NP; i++) {
+                const int pos = t - (K - 1) + i;         // (t + 3 < Lp: t is a multiple of 4 below L, Lp a multiple of 4)
+                e[q][i] = xr[pos < 0 ? 0 : pos];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < GB; q++) {
+            const bool live = g0 + q < ng;               // (a batch past the last group: clamped loads, zero weights -- no branch)
+            const int g = live ? g0 + q : ng - 1;
+            const float wl = live ? 1.0f : 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                float sv[NP];
+#pragma unroll
+                for (int i = 0; i < NP; i++) {
+                    const unsigned wd = j < 2 ? e[q][i].x : (j < 4 ? e[q][i].y : (j < 6 ? e[q][i].z : e[q][i].w));
+                    const float v = __uint_as_float((j & 1) ? (wd & 0xffff0000u) : (wd << 16));
+                    sv[i] = (t - (K - 1) + i) >= 0 ? v : 0.0f;              // causal zero padding
+                }
+                const int c = g * 8 + j;
+#pragma unroll
+                for (int k = 0; k < K; k++) {
+                    const float wv = w[c * K + k] * wl;
+#pragma unroll
+                    for (int i = 0; i < NO; i++) acc[i] = __builtin_fmaf(wv, sv[i + k], acc[i]);
+                }
+            }
+        }
+    }
+    float *o = out + (long)u * out_stride + t;
+#pragma unroll
+    for (int i = 0; i < NO; i++) acc[i] = fminf(fmaxf(acc[i], -1.0f), 1.0f);
+    if (vec_store && t + NO <= L) {
+        *reinterpret_cast<float4 *>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < NO; i++)
+            if (t + i < L) o[i] = acc[i];
+    }
+}
+
+hipError_t launch_final_conv_packed(const unsigned short *xb, float *out, const float *w, const float *bias, int C, int K, int G, int L, int Lp,
+                                    long out_stride, hipStream_t s) {
+    if (G <= 0 || L <= 0) return hipSuccess;
+    if (K != 7 || (Lp & 3) || (C & 7) || !xb || ((uintptr_t)xb & 15)) return hipErrorInvalidValue;
+    const int vec = ((out_stride & 3) == 0 && ((uintptr_t)out & 15) == 0) ? 1 : 0;
+    const int nthr = (L + 3) / 4;
+    hipLaunchKernelGGL((final_conv_packed_kernel<7>), dim3((nthr + 255) / 256, G), dim3(256), 0, s, reinterpret_cast<const uint4 *>(xb), out, w, bias, C,
+                       G, L, Lp, out_stride, vec);
+    return hipGetLastError();
+}
+
 hipError_t launch_final_conv(const float *x, float *out, const float *w, const float *bias, const float *sn_a,
-                             const float *sn_ib, int C, int K, int G, int L, int Lp, long out_stride, hipStream_t s, bool fast_snake) {
+                             const float *sn_ib, int C, int K, int G, int L, int Lp, long out_stride, hipStream_t s, bool fast_snake, bool round_act) {
     if (G <= 0 || L <= 0) return hipSuccess;
     if (K != 7 || (Lp & 3) || ((uintptr_t)x & 15)) return hipErrorInvalidValue;
     int vec = ((out_stride & 3) == 0 && ((uintptr_t)out & 15) == 0) ? 1 : 0;
     int nthr = (L + 3) / 4;
     if ((sn_a == nullptr) != (sn_ib == nullptr)) return hipErrorInvalidValue;
-    if (sn_a && fast_snake)
+    if (round_act && !(sn_a && fast_snake)) return hipErrorInvalidValue;      // (only the bf16 mode's raw-input form rounds)
+    if (round_act)
+        hipLaunchKernelGGL((final_conv_kernel<7, true, true, true>), dim3((nthr + 255) / 256, G), dim3(256), 0, s, x, out, w, bias, sn_a, sn_ib, C,
+                           G, L, Lp, out_stride, vec);
+    else if (sn_a && fast_snake)
         hipLaunchKernelGGL((final_conv_kernel<7, true, true>), dim3((nthr + 255) / 256, G), dim3(256), 0, s, x, out, w, bias, sn_a, sn_ib, C,
                            G, L, Lp, out_stride, vec);
     else if (sn_a)

@@ -22,7 +22,7 @@ EXPORTS = [
     "hipvoc_device_count", "hipvoc_find_vocoder_model", "hipvoc_load", "hipvoc_max_tokens", "hipvoc_n_codebooks", "hipvoc_vocode_pcm16_batch", "hipvoc_unit_samples", "hipvoc_run",
     "hipvoc_decode", "hipvoc_decode_batch", "hipvoc_vocode_pcm16", "hipvoc_decode_units_device", "hipvoc_decode_units_device_noalloc",
     "hipvoc_sync",
-    "hipvoc_stream", "hipvoc_group_units", "hipvoc_unit_macs", "hipvoc_num_stages", "hipvoc_debug_stage",
+    "hipvoc_stream", "hipvoc_group_units", "hipvoc_lanes", "hipvoc_unit_macs", "hipvoc_num_stages", "hipvoc_debug_stage",
     "hipvoc_set_profile", "hipvoc_last_profile", "hipvoc_last_error", "hipvoc_free",
 ]
 
@@ -69,6 +69,7 @@ def load_library():
     L.hipvoc_stream.restype = vp
     L.hipvoc_stream.argtypes = [vp]
     L.hipvoc_group_units.argtypes = [vp]
+    L.hipvoc_lanes.argtypes = [vp]
     L.hipvoc_unit_macs.restype = C.c_int64
     L.hipvoc_unit_macs.argtypes = [vp]
     L.hipvoc_num_stages.argtypes = [vp]
@@ -209,6 +210,11 @@ class HipVocoder:
     @property
     def group_units(self) -> int:
         return int(self._L.hipvoc_group_units(self._h))
+
+    @property
+    def lanes(self) -> int:
+        """Passes of one call in flight side by side (hipvoc_lanes; 2 in the bf16 mode unless HIPVOC_LANES says otherwise)."""
+        return int(self._L.hipvoc_lanes(self._h))
 
     @property
     def unit_macs(self) -> int:

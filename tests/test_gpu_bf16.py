@@ -137,7 +137,8 @@ def test_bf16_packed_dataflow_equals_fp32_exchange_bitwise(pkg, synth, cfg_name,
     """Production bf16 plans exchange GEMM-to-GEMM tensors of the decoder stack as packed bf16 with the consumer's
     SnakeBeta applied by the producer (ConvGemmArgs::xb / yb); HIPVOC_PACKED=0 keeps them fp32 and rounds in the
     consumer.  Same fp32 values rounded at the same point: the waveforms must be identical.  (With the residual stream in fp32
-    on both sides, HIPVOC_RES_BF16=0: the fp32 exchange has no bf16 stream, see test_bf16_residual_stream_in_bf16.)"""
+    and an fp32 input of the final conv on both sides, HIPVOC_RES_BF16=0 HIPVOC_FIN_BF16=0: the fp32 exchange has neither, see
+    test_bf16_residual_stream_in_bf16.)"""
     cfg = getattr(synth, cfg_name)
     path = os.path.join(tempfile.gettempdir(), f"hipvoc_test_{cfg_name}_0.safetensors")
     if not os.path.exists(path):
@@ -145,14 +146,16 @@ def test_bf16_packed_dataflow_equals_fp32_exchange_bitwise(pkg, synth, cfg_name,
     codes = synth.make_codes(frames, 11, cfg)
     old = os.environ.get("HIPVOC_PACKED")
     old_rb = os.environ.get("HIPVOC_RES_BF16")
+    old_fb = os.environ.get("HIPVOC_FIN_BF16")
     try:
         os.environ["HIPVOC_RES_BF16"] = "0"
+        os.environ["HIPVOC_FIN_BF16"] = "0"
         os.environ["HIPVOC_PACKED"] = "0"
         plain = pkg.HipVocoder.load(path, device=0, unit_frames=unit, dtype=BF16)
         os.environ["HIPVOC_PACKED"] = "1"
         packed = pkg.HipVocoder.load(path, device=0, unit_frames=unit, dtype=BF16)
     finally:
-        for k, o in (("HIPVOC_PACKED", old), ("HIPVOC_RES_BF16", old_rb)):
+        for k, o in (("HIPVOC_PACKED", old), ("HIPVOC_RES_BF16", old_rb), ("HIPVOC_FIN_BF16", old_fb)):
             if o is None:
                 os.environ.pop(k, None)
             else:
@@ -405,7 +408,8 @@ def test_two_lanes_of_one_handle_bitwise_and_ordered(pkg, synth, dtype, n_units,
 def test_bf16_residual_stream_in_bf16(pkg, synth, vo, cfg_name, unit, frames, monkeypatch):
     """bf16 mode, packed exchange: the residual stream of the decoder blocks whose residual units are single fused launches that
     exchange it through HBM (block 2 of the full model; HIPVOC_RES_BF16=7: blocks 0 and 1 too, =0: fp32 everywhere as in round 2) is
-    rounded to bf16 wherever it is written and kept as a packed tensor (ConvGemmArgs::rbf).  (a) The debug plans keep the stream as fp32 tensors that hold the rounded values: their last stage is the production
+    rounded to bf16 wherever it is written and kept as a packed tensor (ConvGemmArgs::rbf); and the final conv filters the packed bf16
+    tensor of its activated input (HIPVOC_FIN_BF16=0: fp32).  (a) The debug plans keep the stream as fp32 tensors that hold the rounded values: their last stage is the production
     waveform bit for bit (both forms of every epilogue round at the same point).  (b) What the rounding costs: the two waveforms agree
     to 35 dB or better (40 dB on the full model), and each is inside the mode's gate against the fp32 oracle."""
     cfg = getattr(synth, cfg_name)
@@ -422,6 +426,7 @@ def test_bf16_residual_stream_in_bf16(pkg, synth, vo, cfg_name, unit, frames, mo
             monkeypatch.delenv("HIPVOC_RES_BF16", raising=False)
         else:
             monkeypatch.setenv("HIPVOC_RES_BF16", rb)              # read at load
+        monkeypatch.setenv("HIPVOC_FIN_BF16", "0" if rb == "0" else "1")     # ... and the final conv's input packed bf16 / fp32
         v = pkg.HipVocoder.load(path, device=0, unit_frames=unit, dtype=BF16)
         got = v.synthesize(codes)
         whole = v.run(padded)                                       # the whole padded unit, as the last stage holds it
@@ -433,6 +438,7 @@ def test_bf16_residual_stream_in_bf16(pkg, synth, vo, cfg_name, unit, frames, mo
             v.synthesize(codes)
             names = sorted(v.last_profile())
             assert any("resunit_bf16_ring_kernel<6,true>" in k for k in names) == (rb != "0"), names
+            assert any("final_conv_packed_kernel<7>" in k for k in names) == (rb != "0"), names
         outs[rb] = got
         v.close()
     print(f"{cfg_name} T={unit}: bf16 stream (default / all blocks) vs fp32 stream {snr_db(outs['0'], outs['auto']):.1f} / {snr_db(outs['0'], outs['7']):.1f} dB; "
