@@ -379,7 +379,7 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvGemmArgs &a, const 
 #ifndef EPI_ABL
 #define EPI_ABL 0          // timing-only experiments: 1 = no residual loads (zeros), 2 = no fp32 stores beside a packed output
 #endif
-        if (ru && a.rbf == 2) {                   // packed bf16 residual (S == 1 or phase-major rows: host)
+        if (ru && a.rbi == 2) {                   // packed bf16 residual (S == 1 or phase-major rows: host)
             const unsigned short *rrb = rbf_packed(a.res, ru);
 #pragma unroll
             for (int g = 0; g < 2; g++) {
@@ -543,7 +543,7 @@ __device__ __forceinline__ void fused_epilogue_tile(const ConvGemmArgs &a, const
 }
 
 // The residual of one 32-row output tile of a fused unit, as the kernels request it ahead of the 1x1 product: four 8-byte pieces of
-// the packed bf16 stream (ConvGemmArgs::rbf == 2; resu = a.res + unit * y_us) -- register 4g + j of the tile is channel
+// the packed bf16 stream (ConvGemmArgs::rbi == 2; resu = a.res + unit * y_us) -- register 4g + j of the tile is channel
 // rbase + 8g + j (rbase = 32 o + 4 h) -- unpacked where the epilogue needs the values.
 struct ResPacked { uint2 q[4]; };
 __device__ __forceinline__ void fused_fetch_res_packed(const ConvGemmArgs &a, const float *resu, int rbase, int m, bool ok, ResPacked &d) {     // ok: m < M; N % 8 == 0

@@ -793,7 +793,7 @@ struct PlanBuilder {
         return (float *)ptr;
     }
 
-    int rbf = 0;                   // ConvGemmArgs::rbf of the NEXT gemm / res_unit_fused step (reset by it)
+    int rbf = 0, rbi = -1;         // ConvGemmArgs::rbf / rbi of the NEXT gemm / res_unit_fused step (reset by it); rbi < 0: as rbf says
     void add(const char *name, const char *kernel, double macs, std::function<hipError_t(hipStream_t)> f) {
         p->steps.push_back(Step{std::move(f), name, kernel, macs, 0.0, -1, nullptr, 0, 0, 0});
     }
@@ -808,8 +808,10 @@ struct PlanBuilder {
               const unsigned short *xb = nullptr, unsigned short *yb = nullptr, int in_elu = 0, int s2d = 0) {
         ConvGemmArgs a{};
         a.rbf = rbf;
-        const int rb = rbf;
+        a.rbi = rbi >= 0 ? rbi : (rbf == 2 ? 2 : 0);
+        const int rb = rbf, rbl = a.rbi;
         rbf = 0;
+        rbi = -1;
         a.in_elu = in_elu;
         a.s2d = s2d;
         a.ww = g.ww;
@@ -834,7 +836,7 @@ struct PlanBuilder {
         {
             const double in_el = (double)g.Cin * G * Lin, out_el = (double)(g.N / g.S) * G * ((double)M * g.S);
             p->steps.back().bytes = in_el * (xb ? 2 : 4) + (y ? out_el * (rb == 2 ? 2 : 4) : 0) + (yb ? out_el * 2 : 0) + (post && y2 ? out_el * 4 : 0) +
-                                    (res ? out_el * (rb == 2 ? 2 : 4) : 0);
+                                    (res ? out_el * (rbl == 2 ? 2 : 4) : 0);
         }
     }
 
@@ -849,8 +851,10 @@ struct PlanBuilder {
                         int L, int Lp, float *y, const Snake *post, const unsigned short *xb = nullptr, unsigned short *yb = nullptr) {
         ConvGemmArgs a{};
         a.rbf = rbf;
-        const int rb = rbf;
+        a.rbi = rbi >= 0 ? rbi : (rbf == 2 ? 2 : 0);
+        const int rb = rbf, rbl = a.rbi;
         rbf = 0;
+        rbi = -1;
         a.psn_a = post ? post->ea : nullptr; a.psn_ib = post ? post->ib : nullptr;
         a.x = x; a.y = y; a.w = c1.w; a.wb = c1.wb; a.bias = c1.bias; a.res = x; a.sn_a = s1.ea; a.sn_ib = s1.ib;
         a.xb = xb; a.yb = yb;
@@ -863,7 +867,7 @@ struct PlanBuilder {
         add(name, conv_gemm_kernel_name(a), macs, [a](hipStream_t s) { return launch_conv_gemm(a, s); });
         {
             const double el = (double)c1.N * G * L;      // operand in (packed or fp32), fp32 residual in, fp32 / packed out
-            p->steps.back().bytes = el * (xb ? 2 : 4) + (xb ? el * (rb == 2 ? 2 : 4) : 0) + (y ? el * (rb == 2 ? 2 : 4) : 0) + (yb ? el * 2 : 0);
+            p->steps.back().bytes = el * (xb ? 2 : 4) + (xb ? el * (rbl == 2 ? 2 : 4) : 0) + (y ? el * (rb == 2 ? 2 : 4) : 0) + (yb ? el * 2 : 0);
         }
     }
     // The same residual unit as ONE Winograd kernel (kernels_wino.hip: wino_ps_kernel<D, 3, true>; N = Cin = 96): conv7 by F(2,7),
@@ -1080,9 +1084,14 @@ static std::unique_ptr<Plan> build_plan(Ctx *c, int G, int T, bool debug, char *
             // final conv.  Production plans keep it as a packed tensor in the fp32 buffers' memory (2), debug plans as fp32 tensors
             // that hold the rounded values (1): the same values, so the stage taps show what the production path computes.
             const bool rbf_on = c->res_bf16_auto ? fused_blk : ((c->res_bf16 >> std::min<size_t>(bi, 31)) & 1u) != 0;
-            const int rbf = (rbf_on && !(blk.ws3 && fused_blk) && bi + 1 < c->blocks.size()) ? (debug ? 1 : 2) : 0;
+            const bool walkable = blk.ws3 && fused_blk;
+            const int rbf = (rbf_on && !walkable && bi + 1 < c->blocks.size()) ? (debug ? 1 : 2) : 0;
+            // The block that walks: only what its trans-conv hands it -- the stream as the block starts -- goes through HBM, and is
+            // rounded (the walk's two forms, HIPVOC_BLK3, take the same packed tensor: the first unit reads it, rbi, and writes fp32).
+            const int rbf_tc = (rbf_on && walkable) ? (debug ? 1 : 2) : rbf;
             // trans-conv: packed in; x0 (the residual stream) and packed snake_s1(x0) out
-            b.rbf = rbf;
+            b.rbf = rbf_tc;
+            b.rbi = 0;
             b.gemm(tcn[ni], blk.tc, nullptr, L, Lp, t1, Lp2, nullptr, nullptr, nullptr, ACT_NONE, &blk.res[0].s1, nullptr, pk[pc],
                    pk[pc ^ 1]);
             std::swap(cur, t1);
@@ -1095,6 +1104,7 @@ static std::unique_ptr<Plan> build_plan(Ctx *c, int G, int T, bool debug, char *
                 const bool lastb = bi + 1 == c->blocks.size();
                 ResBlock3Args a{};
                 a.xb = pk[pc]; a.x = cur; a.ws = blk.ws3;
+                a.xrb = rbf_tc == 2 ? 1 : 0;
                 const bool to_fin = lastb && fin_b && fin_post;        // the final conv takes the packed activated tensor
                 a.y = (lastb && !to_fin) ? t1 : nullptr;
                 a.yb = (lastb && !to_fin) ? nullptr : pk[pc ^ 1];
@@ -1108,10 +1118,10 @@ static std::unique_ptr<Plan> build_plan(Ctx *c, int G, int T, bool debug, char *
                 a.G = G; a.L = L; a.us = Lp; a.cs = (long)G * Lp;
                 double macs = 0;
                 for (int u = 0; u < 3; u++) macs += (double)G * L * blk.res[u].c1.N * ((double)blk.res[u].c1.Cin * blk.res[u].c1.ntaps + blk.res[u].c2.Cin);
-                b.add(rbn[ni], "resblock3_bf16_kernel", macs, [a](hipStream_t s) { return launch_resblock3_bf16(a, s); });
+                b.add(rbn[ni], a.xrb ? "resblock3_bf16_kernel<true>" : "resblock3_bf16_kernel<false>", macs, [a](hipStream_t s) { return launch_resblock3_bf16(a, s); });
                 {
                     const double el = (double)C * G * L;             // packed operand + fp32 residual in, fp32 or packed out
-                    b.p->steps.back().bytes = el * (2 + 4) + el * ((lastb && !to_fin) ? 4 : 2);
+                    b.p->steps.back().bytes = el * (2 + (a.xrb ? 2 : 4)) + el * ((lastb && !to_fin) ? 4 : 2);
                 }
                 if (lastb && !to_fin) std::swap(cur, t1); else pc ^= 1;
                 if (lastb && !to_fin) b.mark(st + 2, cur, C, L, Lp);
@@ -1127,9 +1137,11 @@ static std::unique_ptr<Plan> build_plan(Ctx *c, int G, int T, bool debug, char *
                 const bool need_f32 = u < 2 || (last && !to_fin) || debug;   // the residual stream goes on / the final conv
                 // (the third unit's raw output is not part of the stream: nothing but a debug plan's stage tap reads it)
                 const int rbf_u = u < 2 ? rbf : (rbf == 2 ? 2 : 0);
+                const int rbi_u = (walkable && u == 0 && rbf_tc == 2) ? 2 : -1;      // (the walking block unit by unit)
                 if (fused_blk) {
                     unsigned short *ybo = (last && !to_fin) ? nullptr : pk[pc ^ 1];
                     b.rbf = rbf_u;
+                    b.rbi = rbi_u;
                     b.res_unit_fused(run[ni], ru.c1, ru.c2, ru.s1, ru.s2, cur, L, Lp, need_f32 ? t1 : nullptr, next, pk[pc], ybo);
                     if (need_f32) std::swap(cur, t1);
                     if (ybo) pc ^= 1;
@@ -1140,6 +1152,7 @@ static std::unique_ptr<Plan> build_plan(Ctx *c, int G, int T, bool debug, char *
                     pc ^= 1;
                     unsigned short *ybo = (last && !to_fin) ? nullptr : pk[pc ^ 1];      // (the unit's input: no longer needed)
                     b.rbf = rbf_u;
+                    b.rbi = rbi_u;
                     b.gemm(c1n[ni], ru.c2, nullptr, L, Lp, need_f32 ? cur : nullptr, Lp, nullptr, cur, nullptr, ACT_NONE, next, nullptr,
                            pk[pc], ybo);
                     if (ybo) pc ^= 1;

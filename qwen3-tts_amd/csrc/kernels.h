@@ -78,6 +78,9 @@ struct ConvGemmArgs {
     // plans, the fp32 exchange); 2: y and res POINT TO packed bf16 tensors in the layout and strides of yb (the float types of the
     // two fields are then nominal; needs yb, (N/S) % 8 == 0, S == 1 or pm != 0).  Same values either way, bit for bit.
     int rbf;
+    // ... and of the residual READ by this step (res): 2 = packed bf16 tensor, else fp32.  (Apart from the units that open the
+    // block that keeps its stream in registers, rbi == 2 goes with rbf == 2.)
+    int rbi;
 };
 hipError_t launch_conv_gemm(const ConvGemmArgs &a, hipStream_t s);
 hipError_t launch_conv_gemm_bf16(const ConvGemmArgs &a, hipStream_t s);
@@ -129,7 +132,8 @@ size_t conv_gemm_lds_bytes(const ConvGemmArgs &a);
 // (dilations 1, 3, 9); bit-identical to three launches of the fused per-unit kernel.
 struct ResBlock3Args {
     const unsigned short *xb;      // packed activated operand of unit 0, snake_s1(x): [C/8][G][Lp] 16-byte elements
-    const float *x;                // the raw residual stream [C][G][Lp]
+    const float *x;                // the raw residual stream [C][G][Lp] -- or, with xrb, the packed bf16 tensor of it (layout of xb)
+    int xrb;
     float *y;                      // fp32 output (the raw value when yb is given, else psn[2](out) if psn[2] is given), or null with yb
     unsigned short *yb;            // optional packed output psn[2](out)
     const unsigned short *ws;      // the block's weight stream: [3 units][24 slots][6 KB] (hipvoc.cpp: blk3_stream)

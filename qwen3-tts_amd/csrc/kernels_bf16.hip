@@ -369,10 +369,10 @@ __device__ __forceinline__ void conv_gemm_bf16_body(const ConvGemmArgs &a, int H
             }
             __syncthreads();
             float resv[16];   // this tile's residual, in flight during its product
-            ResPacked resq;   // ... from the packed bf16 stream (ConvGemmArgs::rbf == 2)
+            ResPacked resq;   // ... from the packed bf16 stream (ConvGemmArgs::rbi == 2)
             {
                 const float *rup = launder_after(a.res, dep2) + (long)unit * a.y_us;
-                if (a.rbf == 2) {
+                if (a.rbi == 2) {
                     fused_fetch_res_packed(a, rup, o * 32 + 4 * h, m, m < a.M, resq);
                 } else {
 #pragma unroll
@@ -408,7 +408,7 @@ __device__ __forceinline__ void conv_gemm_bf16_body(const ConvGemmArgs &a, int H
                 }
             }
             dep2 = acc2[15];
-            if (a.rbf == 2) fused_unpack_res(resq, resv);
+            if (a.rbi == 2) fused_unpack_res(resq, resv);
             fused_epilogue_tile<BN, FS>(a, acc2, resv, Pm, o * 32 + 4 * h, m, yu, ybu);
         }
         return;
@@ -606,9 +606,9 @@ hipError_t launch_conv_gemm_bf16(const ConvGemmArgs &a_in, hipStream_t s) {
     if (a.yb && (((a.N / a.S) & 7) || (a.N % a.S) || ((uintptr_t)a.yb & 15))) return hipErrorInvalidValue;
     if (!a.y && !a.yb) return hipErrorInvalidValue;
     // packed bf16 residual stream behind y / res: grouped rows, whole channel groups, 16-byte aligned, packed mode only
-    if (a.rbf == 2 && (a.wbm || ((a.N / a.S) & 7) || (a.N % a.S) || (a.S > 1 && !a.pm) || (a.y && ((uintptr_t)a.y & 15)) || (a.res && ((uintptr_t)a.res & 15)) ||
-                       (a.y && !a.yb) || a.y2 || a.s2d > 1))
-        return hipErrorInvalidValue;
+    if ((a.rbf == 2 || a.rbi == 2) && (a.wbm || ((a.N / a.S) & 7) || (a.N % a.S) || (a.S > 1 && !a.pm) || a.y2 || a.s2d > 1)) return hipErrorInvalidValue;
+    if (a.rbf == 2 && ((a.y && ((uintptr_t)a.y & 15)) || (a.y && !a.yb))) return hipErrorInvalidValue;
+    if (a.rbi == 2 && a.res && ((uintptr_t)a.res & 15)) return hipErrorInvalidValue;
     // octet-interleaved transposed-conv rows (device_common.h: tconv_oi_epilogue_tile): what that epilogue assumes
     if (a.S > 1 && a.pm == 2 && ((a.S != 4 && a.S != 8) || a.N % (8 * a.S) || a.res || a.rscale || a.act != ACT_NONE || (a.y_cs & 1) || (a.y_us & 1) ||
                                  (a.y && ((uintptr_t)a.y & 7)) || (a.y2 && ((uintptr_t)a.y2 & 7)) || (!a.y && !a.yb)))

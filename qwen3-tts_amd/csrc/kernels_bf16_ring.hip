@@ -499,7 +499,7 @@ constexpr int NTAPS = 7;
 static_assert(4 * XW % (64 * NW) == 0, "every wave issues the same number of activation pieces");
 }  // namespace ringu
 
-// RB: the residual stream is the packed bf16 tensor (ConvGemmArgs::rbf == 2): four 8-byte loads per tile instead of sixteen 4-byte ones
+// RB: the residual stream is the packed bf16 tensor (ConvGemmArgs::rbi == 2): four 8-byte loads per tile instead of sixteen 4-byte ones
 template <int TN, bool RB>
 __global__ __launch_bounds__(ringu::NTH, 2) void resunit_bf16_ring_kernel(ConvGemmArgs a, int tiles_per_unit) {
     using namespace ringu;
@@ -964,7 +964,7 @@ static bool resunit_ring_selected(const ConvGemmArgs &a) {
 bool conv_bf16_ring_selected(const ConvGemmArgs &a) { return conv7_bf16_ring_selected(a) || tconv_ring_selected(a) || resunit_ring_selected(a); }
 
 const char *conv_bf16_ring_kernel_name(const ConvGemmArgs &a) {
-    if (resunit_ring_selected(a)) return a.rbf == 2 ? "resunit_bf16_ring_kernel<6,true>" : "resunit_bf16_ring_kernel<6,false>";
+    if (resunit_ring_selected(a)) return a.rbi == 2 ? "resunit_bf16_ring_kernel<6,true>" : "resunit_bf16_ring_kernel<6,false>";
     if (tconv_ring_selected(a)) return a.pm == 2 ? "conv_bf16_ring_kernel<4,2,2,4>" : "conv_bf16_ring_kernel<5,2,3,3>";
     const int m = ring_mode();
     return m == 1 ? "conv7_bf16_ring_kernel<4>" : (m == 2 ? "conv7_bf16_ring8_kernel<4,8,2>" : "conv_bf16_ring_kernel<4,7,0,4>");
@@ -998,9 +998,9 @@ hipError_t launch_conv_bf16_ring(const ConvGemmArgs &a, hipStream_t s) {
     if (((uintptr_t)a.wb & 15) || ((uintptr_t)a.xb & 15) || (a.yb && ((uintptr_t)a.yb & 15)) || (!a.y && !a.yb) || (a.yb && ((a.N / a.S) & 7)) ||
         (a.y2 && (!a.psn_a || !a.psn_ib || a.yb)) || a.NP < a.N)
         return hipErrorInvalidValue;
-    if (a.rbf == 2 && (((a.N / a.S) & 7) || (a.N % a.S) || (a.S > 1 && !a.pm) || (a.y && ((uintptr_t)a.y & 15)) || (a.res && ((uintptr_t)a.res & 15)) ||
-                       (a.y && !a.yb) || a.y2))
-        return hipErrorInvalidValue;
+    if ((a.rbf == 2 || a.rbi == 2) && (((a.N / a.S) & 7) || (a.N % a.S) || (a.S > 1 && !a.pm) || a.y2)) return hipErrorInvalidValue;
+    if (a.rbf == 2 && ((a.y && ((uintptr_t)a.y & 15)) || (a.y && !a.yb))) return hipErrorInvalidValue;
+    if (a.rbi == 2 && a.res && ((uintptr_t)a.res & 15)) return hipErrorInvalidValue;
     if (resunit_ring_selected(a)) {
         using namespace ringu;
         if (((uintptr_t)a.wb2 & 15) || (a.yb && !a.psn_a) || (a.psn_a && !a.psn_ib)) return hipErrorInvalidValue;
@@ -1020,7 +1020,7 @@ hipError_t launch_conv_bf16_ring(const ConvGemmArgs &a, hipStream_t s) {
             if (e != hipSuccess) return e;
             doneu[dev] = true;
         }
-        if (a.rbf == 2) hipLaunchKernelGGL((resunit_bf16_ring_kernel<6, true>), dim3((unsigned)grid), dim3(NTH), lds, s, a, tiles_per_unit);
+        if (a.rbi == 2) hipLaunchKernelGGL((resunit_bf16_ring_kernel<6, true>), dim3((unsigned)grid), dim3(NTH), lds, s, a, tiles_per_unit);
         else hipLaunchKernelGGL((resunit_bf16_ring_kernel<6, false>), dim3((unsigned)grid), dim3(NTH), lds, s, a, tiles_per_unit);
         return hipGetLastError();
     }

@@ -121,6 +121,9 @@ __device__ __forceinline__ f32x16 b3_mfma(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 #endif
 }
+// XRB: the block's input stream a.x is the packed bf16 tensor its trans-conv wrote (ResBlock3Args::xrb; layout of xb): twelve 8-byte
+// loads per step into the LOWER HALF of each tile's residual registers, unpacked in place where unit 0's epilogue first needs them
+template <bool XRB>
 __global__ __launch_bounds__(blk3::NTH, 2) void resblock3_bf16_kernel(ResBlock3Args a) {
     using namespace blk3;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -199,6 +202,13 @@ __global__ __launch_bounds__(blk3::NTH, 2) void resblock3_bf16_kernel(ResBlock3A
         return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float *>(((unsigned long long)bhi << 32) | blo), 0, 0x7fffffff, 0x00020000);
     };
     unsigned short *ybu = a.yb ? a.yb + (((long)unit * a.us) << 3) : nullptr;
+    // XRB: descriptor of the four channel groups of row tile i of the packed stream (16-byte elements (c/8, unit, pos))
+    const unsigned grp_bytes = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)a.cs * 16u));
+    auto packed_tile_rsrc = [&](int i) -> __amdgpu_buffer_rsrc_t {
+        const unsigned long long ba = reinterpret_cast<unsigned long long>(a.x) + 16ull * (unsigned long long)((long)unit * a.us + (long)(4 * i) * a.cs);
+        const unsigned blo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ba), bhi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ba >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float *>(((unsigned long long)bhi << 32) | blo), 0, 0x7fffffff, 0x00020000);
+    };
 
     f32x16 y[TN];                                                       // the fp32 residual tile, rows (r&3) + 8(r>>2) + 4h of tile i
     int gi = 0;
@@ -272,7 +282,8 @@ hipError_t launch_resblock3_bf16(const ResBlock3Args &a_in, hipStream_t s) {
     if (a.G <= 0 || a.L <= 0) return hipSuccess;
     // host-side shape checks: what the kernel's indexing assumes
     if (!a.xb || !a.x || !a.ws || (!a.y && !a.yb) || ((uintptr_t)a.xb & 15) || ((uintptr_t)a.ws & 15) || (a.yb && ((uintptr_t)a.yb & 15)) ||
-        !resblock3_bf16_supported(blk3::C, a.dil) || a.us < a.L || a.cs < (long)a.G * a.us || (a.cs * (long)blk3::C) >= 0x7fffffffL * 4L)
+        !resblock3_bf16_supported(blk3::C, a.dil) || a.us < a.L || a.cs < (long)a.G * a.us || (a.cs * (long)blk3::C) >= 0x7fffffffL * 4L ||
+        (a.xrb && (((uintptr_t)a.x & 15) || a.cs * 16L * 4L >= 0x7fffffffL)))
         return hipErrorInvalidValue;
     for (int u = 0; u < 3; u++)
         if (!a.bias1[u] || !a.sn2_a[u] || !a.sn2_ib[u] || !a.bias2[u] || (u < 2 && (!a.psn_a[u] || !a.psn_ib[u])) || (!a.psn_a[u] != !a.psn_ib[u]))
@@ -285,7 +296,9 @@ hipError_t launch_resblock3_bf16(const ResBlock3Args &a_in, hipStream_t s) {
     if (e != hipSuccess) return e;
     if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     if (!done[dev]) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(resblock3_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(resblock3_bf16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(resblock3_bf16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         int cu = 0;
         e = hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
@@ -304,7 +317,8 @@ hipError_t launch_resblock3_bf16(const ResBlock3Args &a_in, hipStream_t s) {
     }
     const long grid = (long)a.G * a.spans_per_unit;
     if (grid > 0x7fffffffL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(resblock3_bf16_kernel, dim3((unsigned)grid), dim3(blk3::NTH), blk3::LDS_BYTES, s, a);
+    if (a.xrb) hipLaunchKernelGGL(resblock3_bf16_kernel<true>, dim3((unsigned)grid), dim3(blk3::NTH), blk3::LDS_BYTES, s, a);
+    else hipLaunchKernelGGL(resblock3_bf16_kernel<false>, dim3((unsigned)grid), dim3(blk3::NTH), blk3::LDS_BYTES, s, a);
     return hipGetLastError();
 }
 
