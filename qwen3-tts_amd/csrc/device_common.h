@@ -323,6 +323,8 @@ __device__ __forceinline__ void tconv_pt_epilogue(const ConvGemmArgs &a, const f
     }
 }
 
+struct ResPacked { uint2 q[4]; };      // four 8-byte pieces of the packed bf16 stream: a 32-row tile's residual, requested ahead of its use
+
 // OI: the kernel instance for octet-interleaved transposed convs (pm == 2).  A compile-time choice: as a run-time branch the second
 // epilogue cost the 128-register bf16 kernels spills in every layer (measured: conv7 layers 8x slower).
 template <int BN, bool ENC = false, bool OI = false, bool FAST = false>
@@ -545,7 +547,6 @@ __device__ __forceinline__ void fused_epilogue_tile(const ConvGemmArgs &a, const
 // The residual of one 32-row output tile of a fused unit, as the kernels request it ahead of the 1x1 product: four 8-byte pieces of
 // the packed bf16 stream (ConvGemmArgs::rbi == 2; resu = a.res + unit * y_us) -- register 4g + j of the tile is channel
 // rbase + 8g + j (rbase = 32 o + 4 h) -- unpacked where the epilogue needs the values.
-struct ResPacked { uint2 q[4]; };
 __device__ __forceinline__ void fused_fetch_res_packed(const ConvGemmArgs &a, const float *resu, int rbase, int m, bool ok, ResPacked &d) {     // ok: m < M; N % 8 == 0
     const unsigned short *rrb = rbf_packed(a.res, resu);
 #pragma unroll

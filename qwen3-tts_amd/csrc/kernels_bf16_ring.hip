@@ -259,6 +259,208 @@ __global__ __launch_bounds__(ring::NTH, 2) void conv7_bf16_ring_kernel(ConvGemmA
 }
 
 // ---------------------------------------------------------------------------------------------------
+// ONE tap: the 1x1 conv that closes an un-fused residual unit (blocks 0 / 1: y = res + W2 h + b2, h packed from the unit's conv7;
+// conv1_bf16_ring_kernel<TN>).  With one tap nothing of an activation tile is reused across stages, so the tile has to run ahead
+// like the weights: a ring of THREE stages, each the 32-channel activation tile (16 KB: [4 k-groups][256 positions]) and weight
+// slot (8 KB at TN = 4) of one channel block, 74 KB in all -- two workgroups per CU.  The wait at a stage's barrier is a constant:
+// younger than this stage's pieces are the next stage's XP + WP.  conv_gemm_bf16_kernel<4,false,true>, which this replaces on
+// large launches, fetches each channel block through registers behind a barrier (a global-load latency exposed per 32 channels,
+// twelve to twenty-four per workgroup, for 0.08 ms of MFMA time in a 0.7 ms launch) and then a residual round trip per output
+// tile; here the residual of tile k + 1 is requested before tile k's epilogue.  Per output element the same chain of MFMAs
+// (channel blocks in order, k-steps 0 / 1, lane half h = k-group 2 ks + h) and the same epilogue arithmetic: bit-identical.
+namespace ring1 {
+constexpr int NW = 4, NTH = 64 * NW, PT = 2, BM = 32 * PT * NW;
+constexpr int XBUF = 4 * BM * 16;           // bytes per activation tile
+constexpr int XP = 4 * BM / 64 / NW;        // 1 KB pieces per wave and tile
+constexpr int R = 3;                        // stages in the ring
+}  // namespace ring1
+
+template <int TN>
+__global__ __launch_bounds__(ring1::NTH, 2) void conv1_bf16_ring_kernel(ConvGemmArgs a, int tiles_per_unit, int n_tiles) {
+    using namespace ring1;
+    constexpr int BN = 32 * TN;
+    constexpr int SLOTB = 4 * BN * 16;
+    constexpr int WP = SLOTB / 1024 / NW;
+    constexpr int PPG = BN / 64;
+    static_assert(BN % 64 == 0 && SLOTB % (1024 * NW) == 0, "whole pieces per wave");
+    constexpr int PMB = 4 * BN * 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *Pm = reinterpret_cast<float *>(smem);
+    const unsigned x_lds = (unsigned)(size_t)(rg_lptr_t)(smem + PMB);
+    const unsigned w_lds = x_lds + R * XBUF;
+
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+    const int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    const int nt = id % n_tiles;
+    const int pt_ = id / n_tiles;
+    const int unit = pt_ / tiles_per_unit;
+    const int m0 = (pt_ - unit * tiles_per_unit) * BM;
+    const int n0 = nt * BN;
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int ncb = a.Cin / 32;                     // (host: Cin % 32 == 0, >= 1)
+
+    fill_param_table<BN, false>(a, Pm, n0, tid, NTH);
+
+    // activation pieces of this wave: piece wave + NW j = elements 64 (wave + NW j) + lane of [4 k-groups][BM]; positions past the
+    // input repeat the last one and only reach outputs that are not stored
+    unsigned xvoff[XP];
+#pragma unroll
+    for (int j = 0; j < XP; j++) {
+        const int e = (wave + NW * j) * 64 + lane;
+        const int kg = e / BM, t = e - kg * BM;
+        int pos = m0 + t;
+        pos = pos >= a.Lin ? a.Lin - 1 : pos;
+        xvoff[j] = (unsigned)(((long)kg * a.x_cs + pos) * 16);
+    }
+    const unsigned long long xbase = reinterpret_cast<unsigned long long>(a.xb) + ((unsigned long long)((long)unit * a.x_us) << 4);
+    const unsigned long long xcb_bytes = (unsigned long long)a.x_cs * 64ull;
+    const unsigned long long wbase = reinterpret_cast<unsigned long long>(a.wb) + ((unsigned long long)n0 << 4);
+    const unsigned long long wkg_bytes = (unsigned long long)a.NP * 16ull;
+    const unsigned wlane = (unsigned)lane * 16u;
+    auto dma_stage = [&](int cb, int buf) {
+        const unsigned long long xb_ = xbase + (unsigned long long)cb * xcb_bytes;
+#pragma unroll
+        for (int j = 0; j < XP; j++) rg_dma16(xb_, xvoff[j], x_lds + (unsigned)(buf * XBUF + (wave + NW * j) * 1024));
+        const unsigned long long wb_ = wbase + (unsigned long long)(cb * 4) * wkg_bytes;
+#pragma unroll
+        for (int q = 0; q < WP; q++) {
+            const int p = wave * WP + q, kg = p / PPG, part = p - kg * PPG;
+            rg_dma16(wb_ + (unsigned long long)kg * wkg_bytes + (unsigned long long)(part * 1024), wlane, w_lds + (unsigned)(buf * SLOTB + p * 1024));
+        }
+    };
+
+    f32x16 acc[TN][PT];
+#pragma unroll
+    for (int i = 0; i < TN; i++)
+#pragma unroll
+        for (int p = 0; p < PT; p++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][p][r] = 0.0f;
+
+    dma_stage(0, 0);
+    if (ncb > 1) dma_stage(1, 1);
+
+    const unsigned xaddr0 = x_lds + (unsigned)((h * BM + wave * 64 + l31) * 16);
+    const unsigned waddr0 = w_lds + (unsigned)((h * BN + l31) * 16);
+    int buf = 0;
+    for (int cb = 0; cb < ncb; cb++) {
+        // this wave's pieces of stage cb have landed (younger: the next stage's); then every wave's, and every wave is past stage
+        // cb - 1, whose buffers take stage cb + 2
+        if (cb + 1 < ncb) rg_wait_bar<XP + WP>();
+        else rg_wait_bar<0>();
+        if (cb + 2 < ncb) dma_stage(cb + 2, buf == 0 ? 2 : buf - 1);
+        const unsigned xa = xaddr0 + (unsigned)(buf * XBUF);
+        const unsigned wa = waddr0 + (unsigned)(buf * SLOTB);
+        rg_bf16x8 aq[2][TN], bq[2][PT];
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+            for (int p = 0; p < PT; p++) bq[ks][p] = rg_lds16(xa + (unsigned)(ks * 2 * BM * 16 + p * 512));
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+            for (int i = 0; i < TN; i++) aq[ks][i] = rg_lds16(wa + (unsigned)(ks * 2 * BN * 16 + i * 512));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+            for (int i = 0; i < TN; i++)
+#pragma unroll
+                for (int p = 0; p < PT; p++) acc[i][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[ks][i], bq[ks][p], acc[i][p], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        buf = buf == R - 1 ? 0 : buf + 1;
+    }
+
+    // epilogue, lean (S == 1, every row exists, bias + residual + optional SnakeBeta; the arithmetic of conv_epilogue_tile in its order:
+    // (acc + bias), residual + that, SnakeBeta on row pairs): per tile the residual of the NEXT tile is requested first
+    float *yu = a.y ? a.y + (long)unit * a.y_us : nullptr;
+    const float *ru0 = launder_after(a.res, acc[TN - 1][PT - 1][15]);
+    const float *ru = ru0 + (long)unit * a.y_us;                           // (host: res != null)
+    unsigned short *ybu0 = launder_after(a.yb, acc[TN - 1][PT - 1][15]);
+    unsigned short *ybu = ybu0 + (((long)unit * a.y_us) << 3);             // (host: yb != null)
+    unsigned short *yrb = (yu && a.rbf == 2) ? rbf_packed(a.y, yu) : nullptr;
+    const unsigned short *rrb = a.rbi == 2 ? rbf_packed(a.res, ru) : nullptr;
+    const int mw = m0 + wave * 64 + l31;
+    const bool psn = a.psn_a != nullptr;
+    const int rnd = a.rbf;
+    static_assert(PT == 2 && TN == 4, "the epilogue below is written out for eight tiles per wave");
+    // tile k = (row tile k >> 1, position tile k & 1); channel group g of it: channels n0 + 32 (k >> 1) + 8 g + 4 h .. + 3 at position m
+    auto tile_m = [&](int k) { return mw + 32 * (k & 1); };
+    auto epi = [&](const f32x16 &ac, int k, const float *t) {
+        const int m = tile_m(k);
+        if (m >= a.M) return;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const int row = (k >> 1) * 32 + 8 * g + 4 * h, c = n0 + row;
+            float v[4], w[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                v[j] = ac[4 * g + j] + Pm[row + j];
+                v[j] = t[4 * g + j] + v[j];
+                w[j] = v[j];
+            }
+            if (psn) {
+#pragma unroll
+                for (int j = 0; j < 4; j += 2) {
+                    const f32x2 sv = snake_beta2_t<true>(mk2(v[j], v[j + 1]), mk2(Pm[2 * BN + row + j], Pm[2 * BN + row + j + 1]),
+                                                         mk2(Pm[3 * BN + row + j], Pm[3 * BN + row + j + 1]));
+                    w[j] = sv.x; w[j + 1] = sv.y;
+                }
+            }
+            const long pk = ((((long)(c >> 3) * a.y_cs + m) << 3) + (c & 4));
+            if (yrb) {
+                *reinterpret_cast<uint2 *>(yrb + pk) = pack4_bf16(v[0], v[1], v[2], v[3]);
+            } else if (yu) {
+                float *yp = yu + (long)c * a.y_cs + m;
+#pragma unroll
+                for (int j = 0; j < 4; j++) yp[(long)j * a.y_cs] = rnd ? bf16_round(v[j]) : v[j];
+            }
+            *reinterpret_cast<uint2 *>(ybu + pk) = pack4_bf16(w[0], w[1], w[2], w[3]);
+        }
+    };
+    if (rrb) {
+        ResPacked rq[2];
+        auto fetch = [&](int k) {
+            const int m = tile_m(k) < a.M ? tile_m(k) : a.M - 1;
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int c = n0 + (k >> 1) * 32 + 8 * g + 4 * h;
+                rq[k & 1].q[g] = *reinterpret_cast<const uint2 *>(rrb + ((((long)(c >> 3) * a.y_cs + m) << 3) + (c & 4)));
+            }
+        };
+#define R1_EPI(k_)                                         \
+    {                                                     \
+        if ((k_) + 1 < 8) fetch((k_) + 1);                 \
+        float t[16];                                      \
+        fused_unpack_res(rq[(k_) & 1], t);                 \
+        epi(acc[(k_) >> 1][(k_) & 1], (k_), t);            \
+    }
+        fetch(0);
+        R1_EPI(0) R1_EPI(1) R1_EPI(2) R1_EPI(3) R1_EPI(4) R1_EPI(5) R1_EPI(6) R1_EPI(7)
+#undef R1_EPI
+    } else {
+        float rf[2][16];
+        auto fetch = [&](int k) {
+            const int m = tile_m(k) < a.M ? tile_m(k) : a.M - 1;
+            const float *rp = ru + (long)(n0 + (k >> 1) * 32 + 4 * h) * a.y_cs + m;
+#pragma unroll
+            for (int r = 0; r < 16; r++) rf[k & 1][r] = rp[(long)((r & 3) + 8 * (r >> 2)) * a.y_cs];
+        };
+#define R1_EPI(k_)                                         \
+    {                                                     \
+        if ((k_) + 1 < 8) fetch((k_) + 1);                 \
+        epi(acc[(k_) >> 1][(k_) & 1], (k_), rf[(k_) & 1]); \
+    }
+        fetch(0);
+        R1_EPI(0) R1_EPI(1) R1_EPI(2) R1_EPI(3) R1_EPI(4) R1_EPI(5) R1_EPI(6) R1_EPI(7)
+#undef R1_EPI
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // The 4-wave ring kernel for any tap count >= 2 and any tile height (conv_bf16_ring_kernel<TN, NTAPS, EPI, RW>): also the
 // decoder blocks' TRANSPOSED convs (two taps; rows = (channel, phase) in the octet-interleaved or phase-tile order of
 // device_common.h, EPI = 2 / 3 = ConvGemmArgs::pm).  What differs from the kernel above:
@@ -961,11 +1163,28 @@ static bool resunit_ring_selected(const ConvGemmArgs &a) {
     if ((long)a.x_cs * 16 * 5 >= 0x7fffffffL) return false;
     return true;
 }
-bool conv_bf16_ring_selected(const ConvGemmArgs &a) { return conv7_bf16_ring_selected(a) || tconv_ring_selected(a) || resunit_ring_selected(a); }
+// the 1x1 conv that closes an un-fused residual unit (what conv_gemm_bf16_kernel<4,false,true> runs), on large launches
+static bool conv1_ring_selected(const ConvGemmArgs &a) {
+    if (ring_mode() <= 0) return false;
+    const char *e = getenv("HIPVOC_BF16_RING_C1");              // (read per launch) 0: conv_gemm_bf16_kernel<4,false,true>
+    if (e && atoi(e) == 0) return false;
+    if (!a.wb || a.wb2 || a.wbm || !a.xb || a.sn_a || a.S != 1 || a.ntaps != 1 || a.shift0 != 0 || a.in_elu || a.s2d > 1 || a.act != ACT_NONE || a.rscale || a.y2) return false;
+    if (!a.res || !a.yb || !a.bias || a.N != a.NP || (a.N % 128) || (a.Cin % 32) || a.Cin < 32 || a.units < 1 || a.M < 1 || a.Lin < 1) return false;
+    if (a.psn_a && !a.psn_ib) return false;
+    if ((long)a.x_cs * 16 * 5 >= 0x7fffffffL) return false;
+    // large launches only: below two workgroups per CU the small-launch / 8-wave forms keep the chip fuller
+    const long wgs = (long)((a.M + ring1::BM - 1) / ring1::BM) * a.units * (a.N / 128);
+    const char *t = getenv("HIPVOC_BF16_RING_C1_WGS");
+    return wgs >= (t ? atol(t) : 1024);
+}
+bool conv_bf16_ring_selected(const ConvGemmArgs &a) {
+    return conv7_bf16_ring_selected(a) || tconv_ring_selected(a) || resunit_ring_selected(a) || conv1_ring_selected(a);
+}
 
 const char *conv_bf16_ring_kernel_name(const ConvGemmArgs &a) {
     if (resunit_ring_selected(a)) return a.rbi == 2 ? "resunit_bf16_ring_kernel<6,true>" : "resunit_bf16_ring_kernel<6,false>";
     if (tconv_ring_selected(a)) return a.pm == 2 ? "conv_bf16_ring_kernel<4,2,2,4>" : "conv_bf16_ring_kernel<5,2,3,3>";
+    if (conv1_ring_selected(a)) return "conv1_bf16_ring_kernel<4>";
     const int m = ring_mode();
     return m == 1 ? "conv7_bf16_ring_kernel<4>" : (m == 2 ? "conv7_bf16_ring8_kernel<4,8,2>" : "conv_bf16_ring_kernel<4,7,0,4>");
 }
@@ -1031,6 +1250,27 @@ hipError_t launch_conv_bf16_ring(const ConvGemmArgs &a, hipStream_t s) {
             return ring_launch_general<4, 2, 2, 4>(a, HL, s);
         }
         return ring_launch_general<5, 2, 3, 3>(a, HL, s);
+    }
+    if (conv1_ring_selected(a)) {
+        using namespace ring1;
+        if (a.Lin < a.M || ((uintptr_t)a.res & 15) || (a.y && ((uintptr_t)a.y & 15))) return hipErrorInvalidValue;
+        const int tiles_per_unit = (a.M + BM - 1) / BM;
+        const int n_tiles = a.NP / (32 * TN);
+        const long grid = (long)tiles_per_unit * a.units * n_tiles;
+        if (grid > 0x7fffffffL) return hipErrorInvalidValue;
+        constexpr size_t lds = 4 * 32 * TN * 4 + R * XBUF + (size_t)R * 4 * 32 * TN * 16;
+        static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
+        static std::atomic<bool> done1[64] = {};
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64 && !done1[dev]) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv1_bf16_ring_kernel<TN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            done1[dev] = true;
+        }
+        hipLaunchKernelGGL(conv1_bf16_ring_kernel<TN>, dim3((unsigned)grid), dim3(NTH), lds, s, a, tiles_per_unit, n_tiles);
+        return hipGetLastError();
     }
     if (!conv7_bf16_ring_selected(a)) return hipErrorInvalidValue;
     const int mode = ring_mode();

@@ -367,6 +367,35 @@ def test_bf16_resunit_ring_kernel_bitwise(pkg, synth, unit, frames, n_seq, monke
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), float(np.abs(a - b).max())
 
 
+@pytest.mark.parametrize("unit,frames,n_seq,stream", [(64, 125, 1, None), (64, 64, 9, None), (64, 64, 9, "15"), (7, 33, 40, "15"), (2, 7, 64, None)])
+def test_bf16_conv1_ring_kernel_bitwise(pkg, synth, unit, frames, n_seq, stream, monkeypatch):
+    """bf16 mode, blocks 0 / 1: the 1x1 conv that closes an un-fused residual unit on conv1_bf16_ring_kernel<4> (activation tiles and
+    weight slots of three channel blocks in flight by LDS-DMA, two 4-wave workgroups per CU, the next tile's residual requested before
+    the current tile's epilogue, a lean epilogue) against conv_gemm_bf16_kernel<4,false,true> (HIPVOC_BF16_RING_C1=0): the same MFMA
+    chain and epilogue arithmetic per output element, so the same bits -- forced onto small launches too (HIPVOC_BF16_RING_C1_WGS=1),
+    with the fp32 residual stream of the default and with the packed bf16 one (HIPVOC_RES_BF16=15)."""
+    cfg = synth.FULL
+    path = os.path.join(tempfile.gettempdir(), "hipvoc_test_FULL_0.safetensors")
+    if not os.path.exists(path):
+        synth.save_safetensors(path, weights_for(synth, "FULL", 0), cfg.metadata())
+    seqs = [synth.make_codes(frames, 577 + i, cfg) for i in range(n_seq)]
+    if stream:
+        monkeypatch.setenv("HIPVOC_RES_BF16", stream)
+    monkeypatch.setenv("HIPVOC_BF16_RING_C1_WGS", "1")
+    outs = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("HIPVOC_BF16_RING_C1", mode)           # read at every launch
+        v = pkg.HipVocoder.load(path, device=0, unit_frames=unit, dtype=BF16)
+        v.set_profile(True)
+        outs.append(v.synthesize_batch(seqs))
+        used = sorted(k for k in v.last_profile() if "conv1_bf16_ring" in k)
+        assert used == (["b0_conv1|conv1_bf16_ring_kernel<4>", "b1_conv1|conv1_bf16_ring_kernel<4>"] if mode == "1" else []), (mode, sorted(v.last_profile()))
+        v.close()
+    for a, b in zip(outs[0], outs[1]):
+        assert a.size == b.size and a.size > 0
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), float(np.abs(a - b).max())
+
+
 @pytest.mark.parametrize("dtype,n_units", [(BF16, 200), (0, 150)])
 def test_two_lanes_of_one_handle_bitwise_and_ordered(pkg, synth, dtype, n_units, monkeypatch):
     """hipvoc_decode_units_device with HIPVOC_LANES=2 (the bf16 mode's default) alternates the passes of one call between two streams
