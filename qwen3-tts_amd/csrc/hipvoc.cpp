@@ -128,10 +128,10 @@ struct Ctx {
     bool phase_major = true;   // transposed-conv rows phase-major (HIPVOC_PHASE_MAJOR=0: channel-major)
     bool tconv_oi = true;      // ... octet-interleaved at stride 4 / 8 in the bf16 modes (HIPVOC_TCONV_OI=0: phase-major there too)
     bool packed = true;        // bf16 mode: GEMM-to-GEMM tensors of the decoder stack exchanged as packed bf16 (HIPVOC_PACKED=0: fp32)
-    // bf16 mode, packed exchange: the residual stream of a decoder block in bf16 too (ConvGemmArgs::rbf).  By default in the blocks
-    // whose residual units are single fused launches that exchange the stream through HBM (block 2 of the full model: 0.75 ms of a
-    // 30 ms pass for 0.1 dB); HIPVOC_RES_BF16 = mask, bit b = decoder block b (0: fp32 everywhere -- round 2's arithmetic; 7: blocks
-    // 0 and 1 as well, whose un-fused units gain 0.2 ms each for 0.2 dB each)
+    // bf16 mode, packed exchange: the residual stream of a decoder block in bf16 too (ConvGemmArgs::rbf).  By default in every block
+    // but the first, whose stream is the smallest tensor of the four and the one whose rounding passes through the most layers
+    // (measured per block, DESIGN 7d: block 0 saves 0.3 ms of a 28 ms pass for 0.24 dB; blocks 1 / 2 / 3 0.5 / 0.75 / 0.7 ms for
+    // 0.15 / 0.1 / 0.05 dB); HIPVOC_RES_BF16 = mask, bit b = decoder block b (0: fp32 everywhere -- round 2's arithmetic; 15: all)
     unsigned res_bf16 = 0;
     bool res_bf16_auto = true;
     // bf16 mode, packed exchange: the final conv filters the packed bf16 tensor of its activated input (written by the last residual
@@ -1083,7 +1083,7 @@ static std::unique_ptr<Plan> build_plan(Ctx *c, int G, int T, bool debug, char *
             // (by capability, not by the HIPVOC_BLK3 switch: both forms of that block keep fp32), nor the block that feeds the
             // final conv.  Production plans keep it as a packed tensor in the fp32 buffers' memory (2), debug plans as fp32 tensors
             // that hold the rounded values (1): the same values, so the stage taps show what the production path computes.
-            const bool rbf_on = c->res_bf16_auto ? fused_blk : ((c->res_bf16 >> std::min<size_t>(bi, 31)) & 1u) != 0;
+            const bool rbf_on = c->res_bf16_auto ? bi >= 1 : ((c->res_bf16 >> std::min<size_t>(bi, 31)) & 1u) != 0;
             const bool walkable = blk.ws3 && fused_blk;
             const int rbf = (rbf_on && !walkable && bi + 1 < c->blocks.size()) ? (debug ? 1 : 2) : 0;
             // The block that walks: only what its trans-conv hands it -- the stream as the block starts -- goes through HBM, and is
