@@ -1145,9 +1145,15 @@ static bool tconv_ring_selected(const ConvGemmArgs &a) {
     if ((long)a.x_cs * 16 * 5 >= 0x7fffffffL || a.N % a.S || a.NP < a.N) return false;
     const int tn = detail::conv_gemm_launch_tn(a);
     if (a.pm == 2) return tn == 4 && (a.S == 4 || a.S == 8) && a.N % (8 * a.S) == 0 && a.NP % 128 == 0 && !(a.y_cs & 1) && !(a.y_us & 1);
-    // (stride 3, block 3's: Cin = 192 is twelve stages in all, the launch is its epilogue -- 1.80 ms per pass on either kernel, so
-    // it stays where it was; measured on MI355X for the others, per pass: stride 8 0.80 -> 0.73 ms, 5 1.34 -> 0.98, 4 1.37 -> 1.29)
-    if (a.pm == 3) return tn == a.S && a.S == 5 && (a.N / a.S) % 32 == 0 && a.NP == a.N;
+    // (measured on MI355X, per pass: stride 8 0.80 -> 0.73 ms, 5 1.34 -> 0.98, 4 1.37 -> 1.29)
+    if (a.pm == 3) {
+        if (tn != a.S || (a.N / a.S) % 32 != 0 || a.NP != a.N) return false;
+        if (a.S == 5) return true;
+        // stride 3 (block 3's: Cin = 192 is twelve stages in all, the launch is its epilogue): 1.80 ms on either kernel while it wrote
+        // an fp32 stream; with the packed stream of DESIGN 7d 1.57 -> 1.45 ms here (HIPVOC_BF16_RING_TCONV3=0: the old kernel)
+        const char *e3 = getenv("HIPVOC_BF16_RING_TCONV3");       // (read per launch)
+        return a.S == 3 && !(e3 && atoi(e3) == 0);
+    }
     return false;
 }
 static int ring_unit_mode() {
@@ -1183,7 +1189,7 @@ bool conv_bf16_ring_selected(const ConvGemmArgs &a) {
 
 const char *conv_bf16_ring_kernel_name(const ConvGemmArgs &a) {
     if (resunit_ring_selected(a)) return a.rbi == 2 ? "resunit_bf16_ring_kernel<6,true>" : "resunit_bf16_ring_kernel<6,false>";
-    if (tconv_ring_selected(a)) return a.pm == 2 ? "conv_bf16_ring_kernel<4,2,2,4>" : "conv_bf16_ring_kernel<5,2,3,3>";
+    if (tconv_ring_selected(a)) return a.pm == 2 ? "conv_bf16_ring_kernel<4,2,2,4>" : (a.S == 3 ? "conv_bf16_ring_kernel<3,2,3,4>" : "conv_bf16_ring_kernel<5,2,3,3>");
     if (conv1_ring_selected(a)) return "conv1_bf16_ring_kernel<4>";
     const int m = ring_mode();
     return m == 1 ? "conv7_bf16_ring_kernel<4>" : (m == 2 ? "conv7_bf16_ring8_kernel<4,8,2>" : "conv_bf16_ring_kernel<4,7,0,4>");
@@ -1249,6 +1255,7 @@ hipError_t launch_conv_bf16_ring(const ConvGemmArgs &a, hipStream_t s) {
             if ((a.y && ((uintptr_t)a.y & 7)) || (a.y2 && ((uintptr_t)a.y2 & 7))) return hipErrorInvalidValue;
             return ring_launch_general<4, 2, 2, 4>(a, HL, s);
         }
+        if (a.S == 3) return ring_launch_general<3, 2, 3, 4>(a, HL, s);
         return ring_launch_general<5, 2, 3, 3>(a, HL, s);
     }
     if (conv1_ring_selected(a)) {

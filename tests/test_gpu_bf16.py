@@ -329,7 +329,7 @@ def test_bf16_ring_kernel_general_form_bitwise(pkg, synth, trim_right, unit, fra
         v.set_profile(True)
         outs.append(v.synthesize_batch(seqs))
         used = sorted(k.split("|")[1] for k in v.last_profile() if "conv_bf16_ring_kernel" in k)
-        want = ["conv_bf16_ring_kernel<4,2,2,4>", "conv_bf16_ring_kernel<4,2,2,4>", "conv_bf16_ring_kernel<4,7,0,4>",
+        want = ["conv_bf16_ring_kernel<3,2,3,4>", "conv_bf16_ring_kernel<4,2,2,4>", "conv_bf16_ring_kernel<4,2,2,4>", "conv_bf16_ring_kernel<4,7,0,4>",
                 "conv_bf16_ring_kernel<4,7,0,4>", "conv_bf16_ring_kernel<5,2,3,3>"] if ring != "0" else []
         if (unit < 64 or len(seqs) * ((frames + unit - 1) // unit) < 9) and want:      # (small launches: the first blocks' trans-convs run at a lowered tile height, on the old kernels)
             assert set(used) >= {"conv_bf16_ring_kernel<4,7,0,4>"} and set(used) <= set(want), (ring, sorted(v.last_profile()))
