@@ -247,8 +247,41 @@ __global__ __launch_bounds__(ring::NTH, 2) void conv7_bf16_ring_kernel(ConvGemmA
     float *y2u = y2u0 ? y2u0 + (long)unit * a.y_us : nullptr;
     unsigned short *ybu0 = launder_after(a.yb, acc[TN - 1][PT - 1][15]);
     unsigned short *ybu = ybu0 ? ybu0 + (((long)unit * a.y_us) << 3) : nullptr;
-    // (written out: left as loops, hipcc keeps them rolled -- the body is large -- and the accumulators move to scratch)
     static_assert(PT == 2 && TN <= 6, "the epilogue below is written out for these");
+    // The case every conv7 of the packed plans is (a residual unit's first conv: bias, SnakeBeta, packed bf16 out, nothing else; every
+    // row exists): conv_epilogue_tile's arithmetic in its order, without its per-element offsets and predicates -- one base per
+    // channel group.  HIPVOC_BF16_RING_EPI=0 (dbg bit 1, set by the launcher): the generic epilogue (same bits).
+    if (ybu && !yu && !ru && !y2u && a.bias && a.act == ACT_NONE && !a.rscale && a.N == a.NP && !(a.dbg & 1)) {      // (workgroup-uniform)
+        const bool psn = a.psn_a != nullptr;
+        auto lean = [&](const f32x16 &ac, int i, int m) {
+            if (m >= a.M) return;
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int row = i * 32 + 8 * g + 4 * h, c = n0 + row;
+                float w[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) w[j] = ac[4 * g + j] + Pm[row + j];
+                if (psn) {
+#pragma unroll
+                    for (int j = 0; j < 4; j += 2) {
+                        const f32x2 sv = snake_beta2_t<true>(mk2(w[j], w[j + 1]), mk2(Pm[2 * BN + row + j], Pm[2 * BN + row + j + 1]),
+                                                             mk2(Pm[3 * BN + row + j], Pm[3 * BN + row + j + 1]));
+                        w[j] = sv.x; w[j + 1] = sv.y;
+                    }
+                }
+                *reinterpret_cast<uint2 *>(ybu + ((((long)(c >> 3) * a.y_cs + m) << 3) + (c & 4))) = pack4_bf16(w[0], w[1], w[2], w[3]);
+            }
+        };
+#define RG_LEAN(i_)                                                                      \
+    if constexpr ((i_) < TN) {                                                          \
+        lean(acc[(i_) < TN ? (i_) : 0][0], (i_), m0 + wave * 64 + l31);                  \
+        lean(acc[(i_) < TN ? (i_) : 0][1], (i_), m0 + wave * 64 + 32 + l31);             \
+    }
+        RG_LEAN(0) RG_LEAN(1) RG_LEAN(2) RG_LEAN(3) RG_LEAN(4) RG_LEAN(5)
+#undef RG_LEAN
+        return;
+    }
+    // (written out: left as loops, hipcc keeps them rolled -- the body is large -- and the accumulators move to scratch)
 #define RG_EPI(i_)                                                                                                                    \
     if constexpr ((i_) < TN) {                                                                                                       \
         conv_epilogue_tile<BN, false, false, true>(a, acc[(i_) < TN ? (i_) : 0][0], Pm, n0, (i_)*32 + 4 * h, m0 + wave * 64 + l31, yu, ru, y2u, ybu);      \
@@ -1302,8 +1335,13 @@ hipError_t launch_conv_bf16_ring(const ConvGemmArgs &a, hipStream_t s) {
         if (e != hipSuccess) return e;
         done[dev] = true;
     }
+    ConvGemmArgs b = a;
+    {
+        const char *le = getenv("HIPVOC_BF16_RING_EPI");            // (read per launch) 0: the generic epilogue in conv7_bf16_ring_kernel
+        b.dbg = (le && atoi(le) == 0) ? 1 : 0;
+    }
     if (w8) hipLaunchKernelGGL((conv7_bf16_ring8_kernel<TN, 8, 2>), dim3((unsigned)grid), dim3(512), lds8, s, a, tiles_per_unit, n_tiles);
-    else hipLaunchKernelGGL(conv7_bf16_ring_kernel<TN>, dim3((unsigned)grid), dim3(ring::NTH), lds4, s, a, tiles_per_unit, n_tiles);
+    else hipLaunchKernelGGL(conv7_bf16_ring_kernel<TN>, dim3((unsigned)grid), dim3(ring::NTH), lds4, s, b, tiles_per_unit, n_tiles);
     return hipGetLastError();
 }
 

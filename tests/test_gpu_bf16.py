@@ -280,7 +280,8 @@ def test_bf16_conv7_ring_kernel_bitwise(pkg, synth, unit, frames, n_seq, monkeyp
     """bf16 mode, blocks 0 / 1: the conv7 kernels that stage both operands by LDS-DMA through a ring (kernels_bf16_ring.hip) --
     conv7_bf16_ring_kernel (HIPVOC_BF16_RING=1, the default: 4-wave workgroups of 256 positions, four weight slots) and
     conv7_bf16_ring8_kernel (=2: one 8-wave workgroup of 512 positions per CU, eight slots, operand reads across the stage barrier) --
-    against conv_gemm_bf16_kernel (=0): the same MFMA chain per output element and the same epilogue, so the same bits: a lone
+    against conv_gemm_bf16_kernel (=0): the same MFMA chain per output element and the same epilogue arithmetic (the ring kernel's lean
+    packed-only epilogue and, HIPVOC_BF16_RING_EPI=0, the generic one), so the same bits: a lone
     utterance (first tiles with causal zero padding, ragged last tiles), a full pass, and passes of many short units (several
     units per launch, tiles shorter than a workgroup).  HIPVOC_CONVS_WGS=0 keeps the small-launch conv7 kernel out of the way
     so that every size runs the kernels under test."""
@@ -291,8 +292,9 @@ def test_bf16_conv7_ring_kernel_bitwise(pkg, synth, unit, frames, n_seq, monkeyp
     seqs = [synth.make_codes(frames, 177 + i, cfg) for i in range(n_seq)]
     monkeypatch.setenv("HIPVOC_CONVS_WGS", "0")
     outs = []
-    for ring, name in (("0", None), ("1", "conv7_bf16_ring_kernel"), ("2", "conv7_bf16_ring8_kernel<4,8,2>")):
-        monkeypatch.setenv("HIPVOC_BF16_RING", ring)              # read at every launch
+    for ring, name in (("0", None), ("1", "conv7_bf16_ring_kernel"), ("1g", "conv7_bf16_ring_kernel"), ("2", "conv7_bf16_ring8_kernel<4,8,2>")):
+        monkeypatch.setenv("HIPVOC_BF16_RING", ring[0])           # read at every launch
+        monkeypatch.setenv("HIPVOC_BF16_RING_EPI", "0" if ring == "1g" else "1")      # the generic epilogue instead of the lean packed-only one
         v = pkg.HipVocoder.load(path, device=0, unit_frames=unit, dtype=BF16)
         v.set_profile(True)
         outs.append(v.synthesize_batch(seqs))
