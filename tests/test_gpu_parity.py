@@ -468,13 +468,16 @@ def test_layout_and_placement_switches_do_not_change_a_bit(pkg, synth, monkeypat
         assert "wino_tconv_kernel<false,2,1,4,8>" in ref_names, ref_names
         assert "wino_ps_kernel<1,1,false,2,8>" in ref_names, ref_names                                # decoder[0] / block 0 on one utterance
     else:
-        assert any("_oi_kernel<" in n for n in ref_names) and any("_pt_kernel<" in n for n in ref_names), ref_names
+        # (the octet-interleaved / phase-tile row orders: the old kernels' instances or, bf16 mode, the ring kernel's EPI = 2 / 3 ones)
+        is_oi = lambda n: "_oi_kernel<" in n or (n.startswith("conv_bf16_ring_kernel<") and n.split(",")[2] == "2")
+        is_pt = lambda n: "_pt_kernel<" in n or (n.startswith("conv_bf16_ring_kernel<") and n.split(",")[2] == "3")
+        assert any(is_oi(n) for n in ref_names) and any(is_pt(n) for n in ref_names), ref_names
     switches = [{"HIPVOC_FIN_POST": "0"}]
     switches += [{"HIPVOC_WINO_TCONV_SMALL": "0"}, {"HIPVOC_WINO_TCONV_W4": "0"}, {"HIPVOC_WINO_PS_SMALL": "0"}, {"HIPVOC_GEMMDS_NW": "1"}, {"HIPVOC_GEMM1_DMA": "1"}] if dtype == 0 else [{"HIPVOC_TCONV_OI": "0"}]
     for env in switches:
         small, big, names = run(env)
         if "HIPVOC_TCONV_OI" in env:
-            assert not any("_oi_kernel<" in n or "_pt_kernel<" in n for n in names), names
+            assert not any(is_oi(n) or is_pt(n) for n in names), names
         if "HIPVOC_WINO_TCONV_SMALL" in env:
             assert not any(n.startswith("wino_tconv_kernel<false,1,2,") for n in names), names
         if "HIPVOC_WINO_TCONV_W4" in env:
