@@ -1400,25 +1400,29 @@ static int decode_units_device(Ctx *c, const long long *d_codes, int n_units, fl
         HIPCHK(hipEventRecord(c->lane_ev[0], c->stream));
         HIPCHK(hipStreamWaitEvent(c->stream2, c->lane_ev[0], 0));
     }
-    int k = 0;
-    for (int u0 = 0; u0 < n_units; u0 += c->group, k++) {
+    int k = 0, rc = HIPVOC_OK;
+    for (int u0 = 0; u0 < n_units && rc == HIPVOC_OK; u0 += c->group, k++) {
         int G = std::min(c->group, n_units - u0);
         const int lane = two ? (k & 1) : 0;
         Plan *p = get_plan(c, G, T, false, false, lane);
-        if (!p) return HIPVOC_E_HIP;
-        int rc = run_plan(c, p, d_codes + (size_t)u0 * T * c->n_q, d_out + (size_t)u0 * unit_stride, (long)unit_stride, -1, nullptr,
-                          lane ? c->stream2 : c->stream);
-        if (rc) return rc;
+        if (!p) { rc = HIPVOC_E_HIP; break; }
+        rc = run_plan(c, p, d_codes + (size_t)u0 * T * c->n_q, d_out + (size_t)u0 * unit_stride, (long)unit_stride, -1, nullptr,
+                      lane ? c->stream2 : c->stream);
     }
-    if (two) {                                                  // ... and the handle's stream ends behind both lanes
-        HIPCHK(hipEventRecord(c->lane_ev[1], c->stream2));
-        HIPCHK(hipStreamWaitEvent(c->stream, c->lane_ev[1], 0));
+    if (two) {                                                  // ... and the handle's stream ends behind both lanes -- also when a pass
+        hipError_t e = hipEventRecord(c->lane_ev[1], c->stream2);      // failed to enqueue: whatever the second lane holds is ordered before
+        if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->lane_ev[1], 0);      // the caller's next hipvoc_sync
+        if (e != hipSuccess) {
+            (void)hipStreamSynchronize(c->stream2);
+            if (rc == HIPVOC_OK) { c->err = std::string("lane join: ") + hipGetErrorString(e); rc = HIPVOC_E_HIP; }
+        }
     }
-    return HIPVOC_OK;
+    return rc;
 }
 
 static int sync_check(Ctx *c) {
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->stream2) HIPCHK(hipStreamSynchronize(c->stream2));      // (already behind the handle's stream after every call; belt and braces)
     int flag = 0;
     HIPCHK(hipMemcpy(&flag, c->d_err, sizeof(int), hipMemcpyDeviceToHost));
     if (flag) {
