@@ -1326,6 +1326,69 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : 4)) void gemm_dma_kernel(Co
     float *y2u0 = launder_after(a.y2, acc[TN - 1][15]);
     float *y2u = y2u0 ? y2u0 + (long)unit * a.y_us : nullptr;
     const int m = m0 + wave * 32 + l31;
+    // The 1x1 conv that closes a residual unit (bias + residual, every row exists; then the raw value, SnakeBeta of it, or both side
+    // by side): conv_epilogue_tile's arithmetic in its order without its per-element offsets, predicates and layout bookkeeping -- one
+    // base per tile, the sixteen row offsets wave-uniform -- and with the NEXT tile's residual requested before this tile's
+    // arithmetic (the residual is added in place: in the generic form every tile's loads wait behind the previous tile's stores).
+    // On this chip fp32 VALU instructions take their cycles out of the matrix pipe's time (wino_ps_kernel's header), so an epilogue
+    // is priced in MFMAs.  dbg bit 1 (HIPVOC_GEMMD_EPI=0, set by the launcher): the generic epilogue (same bits).
+    if (ru && a.bias && a.act == ACT_NONE && !a.rscale && a.s2d <= 1 && a.N == a.NP && !(a.dbg & 1)) {       // (workgroup-uniform; the launcher sets dbg bit 1 for tensors of 4 GB and more)
+        const long cs = a.y_cs;
+        const bool okm = m < a.M, psn = a.psn_a != nullptr;
+        const int mc = okm ? m : a.M - 1;
+        // addresses: a wave-uniform base per (tile, register) -- the tensor's base + (32 i + (r&3) + 8 (r>>2)) rows -- plus this lane's
+        // 32-bit BYTE offset (its lane half's four rows and its position; host: the tensor is under 4 GB), the scalar-base form of
+        // the global instructions: no 64-bit address arithmetic in vector registers
+        const unsigned lob = (unsigned)(((long)(n0 + 4 * h) * cs + m) * 4), lobc = (unsigned)(((long)(n0 + 4 * h) * cs + mc) * 4);
+        auto at = [](const float *base, long row_off, unsigned byte_off) -> float * {
+            return reinterpret_cast<float *>(reinterpret_cast<char *>(const_cast<float *>(base + row_off)) + byte_off);
+        };
+        float t[2][16];
+        auto fetch = [&](int i, float *d) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) d[r] = *at(ru, (long)(i * 32 + (r & 3) + 8 * (r >> 2)) * cs, lobc);
+        };
+        // phase A: v = residual + (acc + bias), in the residual's registers (the accumulator tile is dead after it: the next tile's
+        // residual, requested between the phases, takes its place in the register budget); phase B: SnakeBeta and the stores
+        auto tile_a = [&](const f32x16 &ac, int i, float *tt) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = i * 32 + 4 * h + (r & 3) + 8 * (r >> 2);
+                const float v = ac[r] + Pm[row];
+                tt[r] = tt[r] + v;
+            }
+        };
+        auto tile_b = [&](int i, const float *tt) {
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const int row = i * 32 + 4 * h + (r & 3) + 8 * (r >> 2);
+                const long o0 = (long)(i * 32 + (r & 3) + 8 * (r >> 2)) * cs, o1 = o0 + cs;
+                const float v0 = tt[r], v1 = tt[r + 1];
+                if (psn) {
+                    const f32x2 sv = snake_beta2(mk2(v0, v1), mk2(Pm[2 * BN + row], Pm[2 * BN + row + 1]), mk2(Pm[3 * BN + row], Pm[3 * BN + row + 1]));
+                    if (okm) {
+                        if (y2u) { *at(yu, o0, lob) = v0; *at(y2u, o0, lob) = sv.x; *at(yu, o1, lob) = v1; *at(y2u, o1, lob) = sv.y; }
+                        else { *at(yu, o0, lob) = sv.x; *at(yu, o1, lob) = sv.y; }
+                    }
+                } else if (okm) {
+                    *at(yu, o0, lob) = v0;
+                    *at(yu, o1, lob) = v1;
+                }
+            }
+        };
+        static_assert(TN <= 4, "written out for up to four tiles");
+        fetch(0, t[0]);
+#define GD_TILE(i_)                                                   \
+    if constexpr ((i_) < TN) {                                       \
+        tile_a(acc[(i_) < TN ? (i_) : 0], (i_), t[(i_) & 1]);         \
+        if constexpr ((i_) + 1 < TN) fetch((i_) + 1, t[((i_) + 1) & 1]); \
+        asm volatile("" ::: "memory");                               \
+        tile_b((i_), t[(i_) & 1]);                                    \
+    }
+        GD_TILE(0) GD_TILE(1) GD_TILE(2) GD_TILE(3)
+#undef GD_TILE
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TN; i++) conv_epilogue_tile<BN, false>(a, acc[i], Pm, n0, i * 32 + 4 * h, m, yu, ru, y2u);
 }
@@ -1384,7 +1447,12 @@ static hipError_t gemmd_launch_one(const ConvGemmArgs &a, hipStream_t s) {
     const long grid = (long)tiles_per_unit * a.units * n_tiles;
     if (grid > 0x7fffffffL) return hipErrorInvalidValue;
     const size_t lds = sizeof(float) * (4 * 32 * TN + 2 * 16 * BM + 2 * 16 * 32 * TN);
-    hipLaunchKernelGGL((gemm_dma_kernel<TN, NW>), dim3((unsigned)grid), dim3(64 * NW), lds, s, a, tiles_per_unit, n_tiles);
+    ConvGemmArgs b = a;
+    {
+        const char *le = getenv("HIPVOC_GEMMD_EPI");                // (read per launch) 0: the generic epilogue
+        b.dbg = ((le && atoi(le) == 0) || (long)a.NP * a.y_cs * 4 >= 0xffffffffL || a.units * a.y_us > a.y_cs) ? 1 : 0;      // (32-bit byte offsets in the lean form)
+    }
+    hipLaunchKernelGGL((gemm_dma_kernel<TN, NW>), dim3((unsigned)grid), dim3(64 * NW), lds, s, b, tiles_per_unit, n_tiles);
     return hipGetLastError();
 }
 

@@ -441,7 +441,8 @@ def test_layout_and_placement_switches_do_not_change_a_bit(pkg, synth, monkeypat
       HIPVOC_WINO_TCONV_W4=0     fp32: blocks 1/2's trans-convs in 8-wave workgroups of 16-channel blocks instead of 4-wave / 8-channel ones;
       HIPVOC_WINO_PS_SMALL=0     fp32: two row tiles per wave in the conv7 kernels on small launches too (default there: one);
       HIPVOC_GEMMDS_NW=1, HIPVOC_GEMM1_DMA=1   fp32: one-wave workgroups of gemm_dmas_kernel; gemm1_kernel for the layers the
-                                 LDS-DMA kernels otherwise take."""
+                                 LDS-DMA kernels otherwise take;
+      HIPVOC_GEMMD_EPI=0         fp32: the generic epilogue in gemm_dma_kernel instead of the lean one of the residual units' 1x1 convs."""
     cfg = synth.FULL
     voc_for(pkg, synth, "FULL", 0, 64)                         # makes the checkpoint file
     path = os.path.join(tempfile.gettempdir(), "hipvoc_test_FULL_0.safetensors")
@@ -473,6 +474,7 @@ def test_layout_and_placement_switches_do_not_change_a_bit(pkg, synth, monkeypat
         is_pt = lambda n: "_pt_kernel<" in n or (n.startswith("conv_bf16_ring_kernel<") and n.split(",")[2] == "3")
         assert any(is_oi(n) for n in ref_names) and any(is_pt(n) for n in ref_names), ref_names
     switches = [{"HIPVOC_FIN_POST": "0"}]
+    switches += [{"HIPVOC_GEMMD_EPI": "0"}] if dtype == 0 else []     # fp32: gemm_dma_kernel's generic epilogue instead of the lean residual one
     switches += [{"HIPVOC_WINO_TCONV_SMALL": "0"}, {"HIPVOC_WINO_TCONV_W4": "0"}, {"HIPVOC_WINO_PS_SMALL": "0"}, {"HIPVOC_GEMMDS_NW": "1"}, {"HIPVOC_GEMM1_DMA": "1"}] if dtype == 0 else [{"HIPVOC_TCONV_OI": "0"}]
     for env in switches:
         small, big, names = run(env)
