@@ -937,8 +937,35 @@ __global__ __launch_bounds__(ringu::NTH, 2) void resunit_bf16_ring_kernel(ConvGe
             for (int g = 0; g < 2; g++) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2q[o & 1][i * 2 + g], hb[i][g], acc2, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (RB) {
-            fused_unpack_res(resq[o & 1], resv[0]);
-            fused_epilogue_tile<BN, true>(a, acc2, resv[0], Pm, o * 32 + 4 * h, m, yu, ybu);
+            // the production case (packed bf16 stream in, packed stream and / or packed activated tensor out; N == BN: every row
+            // exists): fused_epilogue_tile's arithmetic in its order, one base per channel group, no per-element predicates
+            if (ybu && (!yu || a.rbf == 2) && !(a.dbg & 1)) {                   // (workgroup-uniform)
+                fused_unpack_res(resq[o & 1], resv[0]);
+                if (m < a.M) {
+                    unsigned short *yrb = yu ? rbf_packed(a.y, yu) : nullptr;
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        const int row = o * 32 + 8 * g + 4 * h;
+                        float v[4];
+#pragma unroll
+                        for (int j = 0; j < 4; j++) v[j] = resv[0][4 * g + j] + (acc2[4 * g + j] + Pm[3 * BN + row + j]);
+                        const long pk = ((((long)(row >> 3) * a.y_cs + m) << 3) + (row & 4));
+                        if (yrb) *reinterpret_cast<uint2 *>(yrb + pk) = pack4_bf16(v[0], v[1], v[2], v[3]);
+                        if (a.psn_a) {
+#pragma unroll
+                            for (int j = 0; j < 4; j += 2) {
+                                const f32x2 sv = snake_beta2_t<true>(mk2(v[j], v[j + 1]), mk2(Pm[4 * BN + row + j], Pm[4 * BN + row + j + 1]),
+                                                                     mk2(Pm[5 * BN + row + j], Pm[5 * BN + row + j + 1]));
+                                v[j] = sv.x; v[j + 1] = sv.y;
+                            }
+                        }
+                        *reinterpret_cast<uint2 *>(ybu + pk) = pack4_bf16(v[0], v[1], v[2], v[3]);
+                    }
+                }
+            } else {
+                fused_unpack_res(resq[o & 1], resv[0]);
+                fused_epilogue_tile<BN, true>(a, acc2, resv[0], Pm, o * 32 + 4 * h, m, yu, ybu);
+            }
         } else {
             fused_epilogue_tile<BN, true>(a, acc2, resv[o & 1], Pm, o * 32 + 4 * h, m, yu, ybu);
         }
@@ -1278,7 +1305,12 @@ hipError_t launch_conv_bf16_ring(const ConvGemmArgs &a, hipStream_t s) {
             if (e != hipSuccess) return e;
             doneu[dev] = true;
         }
-        if (a.rbi == 2) hipLaunchKernelGGL((resunit_bf16_ring_kernel<6, true>), dim3((unsigned)grid), dim3(NTH), lds, s, a, tiles_per_unit);
+        ConvGemmArgs b = a;
+        {
+            const char *le = getenv("HIPVOC_BF16_RING_EPI");        // (read per launch) 0: the generic fused epilogue
+            b.dbg = (le && atoi(le) == 0) ? 1 : 0;
+        }
+        if (a.rbi == 2) hipLaunchKernelGGL((resunit_bf16_ring_kernel<6, true>), dim3((unsigned)grid), dim3(NTH), lds, s, b, tiles_per_unit);
         else hipLaunchKernelGGL((resunit_bf16_ring_kernel<6, false>), dim3((unsigned)grid), dim3(NTH), lds, s, a, tiles_per_unit);
         return hipGetLastError();
     }

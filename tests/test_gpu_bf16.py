@@ -355,8 +355,9 @@ def test_bf16_resunit_ring_kernel_bitwise(pkg, synth, unit, frames, n_seq, monke
         synth.save_safetensors(path, weights_for(synth, "FULL", 0), cfg.metadata())
     seqs = [synth.make_codes(frames, 377 + i, cfg) for i in range(n_seq)]
     outs = []
-    for mode, name in (("0", None), ("1", "resunit_bf16_ring_kernel<6,true>")):
-        monkeypatch.setenv("HIPVOC_BF16_RING_UNIT", mode)         # read at every launch
+    for mode, name in (("0", None), ("1", "resunit_bf16_ring_kernel<6,true>"), ("1g", "resunit_bf16_ring_kernel<6,true>")):
+        monkeypatch.setenv("HIPVOC_BF16_RING_UNIT", mode[0])      # read at every launch
+        monkeypatch.setenv("HIPVOC_BF16_RING_EPI", "0" if mode == "1g" else "1")      # the generic fused epilogue instead of the lean one
         v = pkg.HipVocoder.load(path, device=0, unit_frames=unit, dtype=BF16)
         v.set_profile(True)
         outs.append(v.synthesize_batch(seqs))
