@@ -475,3 +475,43 @@ def test_bf16_residual_stream_in_bf16(pkg, synth, vo, cfg_name, unit, frames, mo
     print(f"{cfg_name} T={unit}: bf16 stream (default / all blocks) vs fp32 stream {snr_db(outs['0'], outs['auto']):.1f} / {snr_db(outs['0'], outs['15']):.1f} dB; "
           f"vs the fp32 oracle {snr_db(ref, outs['auto']):.2f} / {snr_db(ref, outs['15']):.2f} / {snr_db(ref, outs['0']):.2f} dB")
     assert snr_db(outs["0"], outs["auto"]) >= 35.0 and snr_db(outs["0"], outs["15"]) >= 35.0
+
+
+def test_bf16_stream_is_the_fp32_value_rounded_once(pkg, synth, monkeypatch):
+    """Where the bf16 residual stream starts (block 1's transposed conv on the full model: everything upstream is the same arithmetic
+    with the stream on or off) the stage tap with the stream on is EXACTLY the fp32 tap rounded to bf16 (nearest even): the stream
+    is rounded once, where it is written, from the value the fp32-stream path stores.  Downstream the two paths differ (that
+    is what the rounding costs, test_bf16_residual_stream_in_bf16); block 0's taps are identical (its stream stays fp32)."""
+    cfg = synth.FULL
+    path = os.path.join(tempfile.gettempdir(), "hipvoc_test_FULL_0.safetensors")
+    if not os.path.exists(path):
+        synth.save_safetensors(path, weights_for(synth, "FULL", 0), cfg.metadata())
+    T = 8
+    codes = synth.make_codes(T, 91, cfg)
+    monkeypatch.delenv("HIPVOC_RES_BF16", raising=False)
+    monkeypatch.delenv("HIPVOC_FIN_BF16", raising=False)
+    on = pkg.HipVocoder.load(path, device=0, unit_frames=T, dtype=BF16)
+    monkeypatch.setenv("HIPVOC_RES_BF16", "0")
+    monkeypatch.setenv("HIPVOC_FIN_BF16", "0")
+    off = pkg.HipVocoder.load(path, device=0, unit_frames=T, dtype=BF16)
+    cap = 2 * 1024 * 1024
+    C1 = cfg.decoder_dim // 4                                       # channels of block 1 (1536 -> 768 -> 384)
+    seen_dec0 = seen_b0 = seen_b1 = False
+    for s in range(1, on.n_stages):
+        a, b = on.stage(codes, s, cap), off.stage(codes, s, cap)
+        assert a.shape == b.shape
+        seen_dec0 = seen_dec0 or a.shape[0] == cfg.decoder_dim      # decoder[0]'s output: the blocks follow
+        if not seen_dec0:
+            continue
+        if a.shape[0] == cfg.decoder_dim // 2:                      # block 0: trans-conv and units, fp32 stream either way
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), s
+            seen_b0 = True
+        if a.shape[0] == C1:                                        # block 1's trans-conv output: the first rounded tensor
+            u = b.view(np.uint32).astype(np.uint64)
+            r = ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)
+            assert np.array_equal(a.view(np.uint32), r), s
+            assert not np.array_equal(a.view(np.uint32), b.view(np.uint32))
+            seen_b1 = True
+            break
+    assert seen_b0 and seen_b1
+    on.close(); off.close()
